@@ -1,0 +1,176 @@
+/*
+ * mspi_hip.h -- C ABI of libmspi_hip.so: the MI355X (gfx950) kernels behind MSPI's
+ * saliency-inference hot path.
+ *
+ * The reference (oraclefina/MSPI) has no FFI boundary on this path: every op below is an
+ * ATen call issued from a torch.nn.Module.forward.  Each entry point
+ * therefore cites the reference call site(s) whose arithmetic it replaces; the Python
+ * host (mspi_amd/) reaches them through ctypes with raw device pointers
+ * (tensor.data_ptr()) and the caller's hipStream_t.  See INTEGRATION.md for the binding.
+ *
+ * Conventions
+ *   - all tensors are fp32, device memory, owned by the caller; nothing is allocated here
+ *   - activations are channels-last: a tensor [N,T,H,W,C] is a row-major matrix of
+ *     M = N*T*H*W rows with a row stride `ld` (floats, multiple of 4) and C columns.
+ *     ld > C lets a producer write straight into a channel slice of a concat buffer.
+ *   - every function returns 0 or a negative MSPI_E* code and never throws; the message
+ *     is available from mspi_last_error() (thread-local)
+ *   - kernels are stateless and re-entrant; launches go to `stream` and return
+ *     immediately (graph-capture safe: no sync, no allocation, no memcpy inside)
+ */
+#ifndef MSPI_HIP_H
+#define MSPI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSPI_ABI_VERSION 1
+
+typedef void* mspi_stream_t; /* hipStream_t */
+
+enum {
+  MSPI_OK = 0,
+  MSPI_EINVAL = -1,   /* bad descriptor (shape/stride/alignment) */
+  MSPI_ELAUNCH = -2,  /* hip launch error */
+  MSPI_ENODEV = -3    /* no gfx950 device / code object not loadable */
+};
+
+enum { MSPI_ACT_NONE = 0, MSPI_ACT_RELU = 1, MSPI_ACT_GELU = 2, MSPI_ACT_SIGMOID = 3, MSPI_ACT_SWISH = 4 };
+
+int mspi_version(void);
+const char* mspi_last_error(void);
+/* number of visible HIP devices whose arch is gfx950 (0 if none). */
+int mspi_device_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * Dense convolution / linear as an MFMA (v_mfma_f32_32x32x2_f32) implicit GEMM.
+ *   y[m, co] = act( sum_k A[m,k] * w[co,k] + bias[co] (+ res[m,co]) )
+ * m runs over (n, to, ho, wo); k over (kt, kh, kw, ci) with ci fastest.
+ * Replaces: nn.Conv3d / nn.Conv2d / nn.Linear with eval-mode BatchNorm folded in --
+ *   SlowFast/resnet_helper.py:296-303,335-342 (X3D a / c), :427-464 (bottleneck a/b/c),
+ *   :579-591 (branch1); SlowFast/stem_helper.py:262-269 (x3d conv_xy), :171-181 (basic stem);
+ *   backbones/resnet.py:79-90,30-52; backbones/s3d.py:41-52,95-116;
+ *   model/model_utils.py:43-46,92-94 (Linear), :324-327 (pwconv), :367-377 (smooth),
+ *   :439-440 (lateral), :490-503 (readout); backbones/MViT.py:1059-1061;
+ *   backbones/video_swin_transformer.py:151-153,449.
+ * The input is addressed through element strides so NCDHW user tensors (clips, audio)
+ * are consumed without a layout pass.  `gate` (optional, 1x1x1 stride-1 only) applies the
+ * X3D squeeze-excite scale and Swish to A on the fly:
+ *   A'[m,k] = swish(A[m,k] * gate[n(m), k])      (SlowFast/resnet_helper.py:66-73,76-103)
+ * ------------------------------------------------------------------------------------ */
+typedef struct MspiConvDesc {
+  int32_t N, T, H, W, C;           /* input extent; C = channels as stored */
+  int64_t sN, sT, sH, sW, sC;      /* input element strides */
+  int32_t kT, kH, kW;
+  int32_t strT, strH, strW;
+  int32_t padT, padH, padW;
+  int32_t To, Ho, Wo;              /* output extent (checked against the formula) */
+  int32_t Cout;                    /* output columns written (stored width) */
+  int64_t ldy;                     /* output row stride */
+  int64_t ldw;                     /* weight row stride, >= kT*kH*kW*C, multiple of 4, zero padded */
+  int64_t ldr;                     /* residual row stride (res != NULL) */
+  int32_t act;                     /* MSPI_ACT_* applied last */
+} MspiConvDesc;
+
+int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float* w, const float* bias /*[Cout] or NULL*/,
+                  const float* res /*NULL or [M][ldr]*/, const float* gate /*NULL or [N][C]*/,
+                  float* y, mspi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Depthwise convolution, channels-last, bias (= folded BN) + activation fused; optional
+ * per-(n,c) sums of the pre-activation output for squeeze-excite (atomics into `pool`,
+ * which the caller zeroes).
+ * Replaces: X3D `b` 3x3x3 (SlowFast/resnet_helper.py:310-319) + b_bn (+ Swish :76-103),
+ *   X3D stem (5,1,1) (SlowFast/stem_helper.py:270-283), ConvNextBlock.dwconv_t/dwconv_s
+ *   (model/model_utils.py:321-322), MViT pool_q/k/v (backbones/MViT.py:1093-1133),
+ *   timm ConvNeXt conv_dw 7x7.
+ * w is [kT*kH*kW][C] (tap-major), x rows have stride ldx, y rows ldy.
+ * ------------------------------------------------------------------------------------ */
+typedef struct MspiDwConvDesc {
+  int32_t N, T, H, W, C;
+  int64_t ldx, ldy;
+  int32_t kT, kH, kW;
+  int32_t strT, strH, strW;
+  int32_t padT, padH, padW;
+  int32_t To, Ho, Wo;
+  int32_t act;
+} MspiDwConvDesc;
+
+int mspi_dwconv_fwd(const MspiDwConvDesc* d, const float* x, const float* w, const float* bias,
+                    float* y, float* pool /*NULL or [N][C]*/, mspi_stream_t stream);
+
+/* Squeeze-excite gate: gate[n,c] = sigmoid(fc2(relu(fc1(pool[n,:] * inv_count))))
+ * (SlowFast/resnet_helper.py:27-73).  w1 [F][C], b1 [F], w2 [C][F], b2 [C]. */
+int mspi_se_gate(const float* pool, float inv_count, const float* w1, const float* b1, const float* w2,
+                 const float* b2, float* gate, int32_t N, int32_t C, int32_t F, mspi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * LayerNorm over the C columns of each row, one wavefront per row:
+ *   y[m,:] = act( (x[m,:]-mean)/sqrt(var+eps) * gamma + beta ) + table[m % P, :]
+ * Replaces nn.LayerNorm at model/model_utils.py:231-233 (+ sinusoid table add :273-274),
+ *   :139,145 (Block), :296 (LayerNorm3d), :404-435 (projector LN+ReLU);
+ *   backbones/MViT.py:1714; backbones/video_swin_transformer.py:306; timm LayerNorm2d.
+ * ------------------------------------------------------------------------------------ */
+int mspi_layernorm_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma,
+                       const float* beta, float eps, int64_t M, int32_t C, int32_t act,
+                       const float* table /*NULL or [P][C]*/, int32_t P, mspi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused multi-head attention (flash style, MFMA, online softmax, fp32):
+ *   o[b,h,i,:] = softmax_j( scale * q[b,h,i,:] . k[b,h,j,:] ) v[b,h,j,:]
+ * q/k/v/o are addressed as base + b*sB + h*sH + token*sT + d (d contiguous).
+ * Replaces model/model_utils.py:102-106 (SyncBlock attention).
+ * head_dim must be a multiple of 32 and <= 128.
+ * ------------------------------------------------------------------------------------ */
+typedef struct MspiAttnDesc {
+  int32_t B, Hh, Nq, Nk, D;
+  int64_t q_sB, q_sH, q_sT;
+  int64_t k_sB, k_sH, k_sT;
+  int64_t v_sB, v_sH, v_sT;
+  int64_t o_sB, o_sH, o_sT;
+  float scale;
+} MspiAttnDesc;
+
+int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float* k, const float* v, float* o,
+                  mspi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Max pooling, channels-last, -inf padding.
+ * Replaces nn.MaxPool3d / MaxPool2d at model/model_utils.py:189,206;
+ *   backbones/resnet.py:82; SlowFast/stem_helper.py:195-197; backbones/MViT.py:1403-1409.
+ * ------------------------------------------------------------------------------------ */
+int mspi_maxpool_fwd(const MspiDwConvDesc* d, const float* x, float* y, mspi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Bilinear spatial up-sampling by an integer factor (align_corners=False; T untouched,
+ * which is what trilinear with scale (1,k,k) computes), optionally accumulating:
+ *   dst[n,t,ho,wo,:] (+)= bilinear(src[n,t,:,:,:])
+ * Replaces nn.Upsample at model/model_utils.py:158,208,486-488,498 and the adds at :566-570.
+ * ------------------------------------------------------------------------------------ */
+int mspi_upsample_fwd(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t NT, int32_t H,
+                      int32_t W, int32_t C, int32_t factor, int32_t accumulate, mspi_stream_t stream);
+
+/* SA gating x*m + x (model/model_utils.py:167-170): x[m,:] *= (1 + mask[m]), in place. */
+int mspi_rowgate(float* x, int64_t ldx, const float* mask, int64_t M, int32_t C, mspi_stream_t stream);
+
+/* out[n,:] -= logsumexp(out[n,:]) over L elements per sample (model/model_utils.py:572). */
+int mspi_logsumexp_sub(float* x, int32_t N, int32_t L, mspi_stream_t stream);
+
+/* out[n,c] = mean over R rows of x[n,r,c] (nn.AdaptiveAvgPool, model/model_utils.py:402-403,543-544). */
+int mspi_mean_rows(const float* x, int64_t ldx, int64_t rows_per_sample_stride, float* out, int32_t N,
+                   int32_t R, int32_t C, mspi_stream_t stream);
+
+/* out[0] (+)= scale * mean_n( -cos(p[n,:], z[n,:]) )   (D(), model/model_utils.py:285-290). */
+int mspi_neg_cosine(const float* p, const float* z, float* out, int32_t N, int32_t C, float scale,
+                    int32_t accumulate, mspi_stream_t stream);
+
+/* y = a + b over n floats (plain residual add where no producer can fuse it). */
+int mspi_add(const float* a, const float* b, float* y, int64_t n, mspi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSPI_HIP_H */

@@ -1,0 +1,55 @@
+// Shared host/device helpers for libmspi_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include "../../include/mspi_hip.h"
+
+namespace mspi {
+
+void set_error(const char* fmt, ...);
+
+// Check a launch; HIP launch errors surface through hipGetLastError (no sync: capture safe).
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return MSPI_ELAUNCH;
+  }
+  return MSPI_OK;
+}
+
+#define MSPI_REQUIRE(cond, ...)   \
+  do {                            \
+    if (!(cond)) {                \
+      mspi::set_error(__VA_ARGS__); \
+      return MSPI_EINVAL;         \
+    }                             \
+  } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case MSPI_ACT_RELU: return fmaxf(v, 0.f);
+    case MSPI_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));  // nn.GELU (erf form)
+    case MSPI_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    case MSPI_ACT_SWISH: return v / (1.f + __expf(-v));
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace mspi

@@ -1,0 +1,328 @@
+// Implicit-GEMM convolution / linear on the fp32 matrix cores of gfx950
+// (v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain, 64 FLOP/clk/SIMD).
+//
+//   y[m, co] = act( sum_k A[m,k] * w[co,k] + bias[co] (+ res[m,co]) )
+//
+// A is never materialised: the k index is (tap, ci) with ci fastest and a row m is an
+// output position (n,to,ho,wo); the loader gathers A straight from the strided input.
+// Tiling is for 64-wide wavefronts: a 256-thread workgroup = 4 waves, each wave owns
+// TM x TN 32x32 accumulator tiles (16 VGPRs each, column on the lane).  The K loop moves
+// BK=32 floats per step through LDS rows padded to 36 floats, so that the ds_read_b128
+// fragment reads (lane (i,h) takes k = 4h..4h+3 of row i: the MFMA K order is permuted
+// identically for A and B, which a dot product does not care about) are conflict-free.
+#include "common.h"
+
+namespace mspi {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+  const float* x;
+  const float* w;
+  const float* bias;
+  const float* res;
+  const float* gate;
+  float* y;
+  int N, T, H, W, C;
+  long sN, sT, sH, sW, sC;
+  int kT, kH, kW, strT, strH, strW, padT, padH, padW;
+  int To, Ho, Wo, Cout;
+  long ldy, ldw, ldr;
+  int act;
+  int M, K;
+  int rows_per_sample;
+  int tiles_n, nblocks;
+};
+
+constexpr int BK = 32;
+constexpr int LDK = 36;  // padded LDS row (floats): 144 B keeps 16-B alignment, kills b128 conflicts
+
+enum { LOAD_V4 = 0, LOAD_S = 1 };
+
+template <int BM, int BN, int WM, int WN, int LOADER>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
+  constexpr int TM = BM / (WM * 32);
+  constexpr int TN = BN / (WN * 32);
+  constexpr int AR = BM / 32;  // A rows staged per thread
+  constexpr int BR = BN / 32;  // B rows staged per thread
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+  float* As = smem;
+  float* Bs = smem + BM * LDK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // XCD-aware, bijective block remap: blocks dealt to one XCD (bid % 8) get consecutive
+  // logical ids, so the N-tiles that re-read one A row panel share that XCD's L2.
+  int logical;
+  {
+    const int bid = blockIdx.x, nwg = p.nblocks;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = logical % p.tiles_n;
+  const int tile_m = logical / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int kv = tid & 7;      // which float4 of the 32-float k chunk
+  const int rbase = tid >> 3;  // 0..31
+
+  // ---- per-row gather state (fixed over the K loop) ----
+  long a_off[AR];
+  int a_t[AR], a_h[AR], a_w[AR], a_n[AR];
+  bool a_ok[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    int m = m0 + rbase + 32 * i;
+    a_ok[i] = m < p.M;
+    if (!a_ok[i]) m = 0;
+    int wo = m % p.Wo;
+    int t1 = m / p.Wo;
+    int ho = t1 % p.Ho;
+    int t2 = t1 / p.Ho;
+    int to = t2 % p.To;
+    int n = t2 / p.To;
+    a_n[i] = n;
+    a_t[i] = to * p.strT - p.padT;
+    a_h[i] = ho * p.strH - p.padH;
+    a_w[i] = wo * p.strW - p.padW;
+    a_off[i] = (long)n * p.sN + (long)a_t[i] * p.sT + (long)a_h[i] * p.sH + (long)a_w[i] * p.sW;
+  }
+  const float* b_ptr[BR];
+  bool b_ok[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    int n = n0 + rbase + 32 * i;
+    b_ok[i] = n < p.Cout;
+    b_ptr[i] = p.w + (long)(b_ok[i] ? n : 0) * p.ldw;
+  }
+
+  // ---- k cursor of this thread's float4 (V4 loader): (tap, c) and tap -> (dt,dh,dw) ----
+  int kc = kv * 4, ktap = 0, kdt = 0, kdh = 0, kdw = 0;
+  if (LOADER == LOAD_V4) {
+    ktap = kc / p.C;
+    kc -= ktap * p.C;
+    int khw = p.kH * p.kW;
+    kdt = ktap / khw;
+    int r = ktap - kdt * khw;
+    kdh = r / p.kW;
+    kdw = r - kdh * p.kW;
+  }
+  const int ntaps = p.kT * p.kH * p.kW;
+
+  float4 ra[AR], rb[BR];
+
+  auto load_tiles = [&](int k0) {
+    const int k = k0 + kv * 4;
+    // B (weights): rows are zero padded to ldw (multiple of 4)
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b_ok[i] && k < p.ldw) v = *reinterpret_cast<const float4*>(b_ptr[i] + k);
+      rb[i] = v;
+    }
+    if (LOADER == LOAD_V4) {
+      const bool kin = ktap < ntaps;
+      const long koff = (long)kdt * p.sT + (long)kdh * p.sH + (long)kdw * p.sW + kc;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool inb = kin && a_ok[i] && (unsigned)(a_t[i] + kdt) < (unsigned)p.T &&
+                         (unsigned)(a_h[i] + kdh) < (unsigned)p.H && (unsigned)(a_w[i] + kdw) < (unsigned)p.W;
+        if (inb) {
+          v = *reinterpret_cast<const float4*>(p.x + a_off[i] + koff);
+          if (p.gate) {
+            const float4 g = *reinterpret_cast<const float4*>(p.gate + (long)a_n[i] * p.C + kc);
+            v.x = act_apply(v.x * g.x, MSPI_ACT_SWISH);
+            v.y = act_apply(v.y * g.y, MSPI_ACT_SWISH);
+            v.z = act_apply(v.z * g.z, MSPI_ACT_SWISH);
+            v.w = act_apply(v.w * g.w, MSPI_ACT_SWISH);
+          }
+        }
+        ra[i] = v;
+      }
+      // advance the cursor by one BK chunk
+      kc += BK;
+      while (kc >= p.C) {
+        kc -= p.C;
+        ++ktap;
+        if (++kdw == p.kW) {
+          kdw = 0;
+          if (++kdh == p.kH) {
+            kdh = 0;
+            ++kdt;
+          }
+        }
+      }
+    } else {
+      float va[AR][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ke = k + e;
+        const int tap = ke / p.C;
+        const int c = ke - tap * p.C;
+        const int khw = p.kH * p.kW;
+        const int dt = tap / khw;
+        const int r = tap - dt * khw;
+        const int dh = r / p.kW;
+        const int dw = r - dh * p.kW;
+        const bool kin = tap < ntaps;
+        const long koff = (long)dt * p.sT + (long)dh * p.sH + (long)dw * p.sW + (long)c * p.sC;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+          const bool inb = kin && a_ok[i] && (unsigned)(a_t[i] + dt) < (unsigned)p.T &&
+                           (unsigned)(a_h[i] + dh) < (unsigned)p.H && (unsigned)(a_w[i] + dw) < (unsigned)p.W;
+          va[i][e] = inb ? p.x[a_off[i] + koff] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < AR; ++i) ra[i] = make_float4(va[i][0], va[i][1], va[i][2], va[i][3]);
+    }
+  };
+
+  v16f acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int Kloop = (int)p.ldw;  // ldw >= K by contract; [K, ldw) is zero in w and masked in A
+  const int li = lane & 31, lh = lane >> 5;
+
+  load_tiles(0);
+  for (int k0 = 0; k0 < Kloop; k0 += BK) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i)
+      *reinterpret_cast<float4*>(&As[(rbase + 32 * i) * LDK + kv * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BR; ++i)
+      *reinterpret_cast<float4*>(&Bs[(rbase + 32 * i) * LDK + kv * 4]) = rb[i];
+    __syncthreads();
+    if (k0 + BK < Kloop) load_tiles(k0 + BK);  // next tile's loads fly under the MFMAs
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const float4*>(&As[((wm * TM + i) * 32 + li) * LDK + kk * 8 + lh * 4]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const float4*>(&Bs[((wn * TN + j) * 32 + li) * LDK + kk * 8 + lh * 4]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + li;
+    if (col >= p.Cout) continue;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rb0 = m0 + (wm * TM + i) * 32 + 4 * lh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rb0 + (r & 3) + 8 * (r >> 2);
+        if (row < p.M) {
+          float v = acc[i][j][r] + bv;
+          if (p.res) v += p.res[(long)row * p.ldr + col];
+          p.y[(long)row * p.ldy + col] = act_apply(v, p.act);
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_cfg(const ConvArgs& a, bool v4, hipStream_t s) {
+  if (v4)
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, LOAD_V4>), dim3(a.nblocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, LOAD_S>), dim3(a.nblocks), dim3(256), 0, s, a);
+}
+
+}  // namespace mspi
+
+using namespace mspi;
+
+extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float* w, const float* bias,
+                             const float* res, const float* gate, float* y, mspi_stream_t stream) {
+  MSPI_REQUIRE(d && x && w && y, "mspi_conv_fwd: null argument");
+  MSPI_REQUIRE(d->N > 0 && d->T > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->Cout > 0, "mspi_conv_fwd: empty extent");
+  MSPI_REQUIRE(d->kT > 0 && d->kH > 0 && d->kW > 0 && d->strT > 0 && d->strH > 0 && d->strW > 0 && d->padT >= 0 &&
+                   d->padH >= 0 && d->padW >= 0,
+               "mspi_conv_fwd: bad kernel/stride/pad");
+  const int To = (d->T + 2 * d->padT - d->kT) / d->strT + 1;
+  const int Ho = (d->H + 2 * d->padH - d->kH) / d->strH + 1;
+  const int Wo = (d->W + 2 * d->padW - d->kW) / d->strW + 1;
+  MSPI_REQUIRE(To == d->To && Ho == d->Ho && Wo == d->Wo && To > 0 && Ho > 0 && Wo > 0,
+               "mspi_conv_fwd: output extent (%d,%d,%d) does not match formula (%d,%d,%d)", d->To, d->Ho, d->Wo, To,
+               Ho, Wo);
+  const long K = (long)d->kT * d->kH * d->kW * d->C;
+  MSPI_REQUIRE(d->ldw >= K && (d->ldw & 3) == 0 && aligned16(w), "mspi_conv_fwd: weight rows must be 16-B aligned, ldw >= K");
+  MSPI_REQUIRE(d->ldy >= d->Cout, "mspi_conv_fwd: ldy < Cout");
+  MSPI_REQUIRE(!res || d->ldr >= d->Cout, "mspi_conv_fwd: ldr < Cout");
+  const long Ml = (long)d->N * To * Ho * Wo;
+  MSPI_REQUIRE(Ml < (1L << 31) && K < (1L << 31), "mspi_conv_fwd: problem too large for 32-bit row index");
+
+  const bool v4 = d->sC == 1 && (d->C & 3) == 0 && aligned16(x) && (d->sN & 3) == 0 && (d->sT & 3) == 0 &&
+                  (d->sH & 3) == 0 && (d->sW & 3) == 0 && (!gate || aligned16(gate));
+  MSPI_REQUIRE(!gate || (v4 && d->kT == 1 && d->kH == 1 && d->kW == 1),
+               "mspi_conv_fwd: gate needs a 1x1x1 conv on a 16-B aligned channels-last input");
+
+  ConvArgs a;
+  a.x = x; a.w = w; a.bias = bias; a.res = res; a.gate = gate; a.y = y;
+  a.N = d->N; a.T = d->T; a.H = d->H; a.W = d->W; a.C = d->C;
+  a.sN = d->sN; a.sT = d->sT; a.sH = d->sH; a.sW = d->sW; a.sC = d->sC;
+  a.kT = d->kT; a.kH = d->kH; a.kW = d->kW;
+  a.strT = d->strT; a.strH = d->strH; a.strW = d->strW;
+  a.padT = d->padT; a.padH = d->padH; a.padW = d->padW;
+  a.To = To; a.Ho = Ho; a.Wo = Wo; a.Cout = d->Cout;
+  a.ldy = d->ldy; a.ldw = d->ldw; a.ldr = d->ldr; a.act = d->act;
+  a.M = (int)Ml; a.K = (int)K; a.rows_per_sample = To * Ho * Wo;
+
+  // tile choice: least padded work, with a penalty for narrow tiles (more LDS traffic per
+  // MFMA) and for grids too small to fill 256 CUs.
+  struct Cfg { int bm, bn; float eff; };
+  static const Cfg cfgs[4] = {{128, 128, 1.00f}, {128, 64, 1.08f}, {128, 32, 1.30f}, {64, 64, 1.25f}};
+  int best = 0;
+  double best_cost = 1e300;
+  for (int i = 0; i < 4; ++i) {
+    const long tm = (Ml + cfgs[i].bm - 1) / cfgs[i].bm, tn = (d->Cout + cfgs[i].bn - 1) / cfgs[i].bn;
+    const long blocks = tm * tn;
+    // time ~ (#waves of resident workgroups) x (work per workgroup)
+    double waves = (double)blocks / 512.0;  // 256 CUs x 2 resident workgroups
+    if (waves < 1.0) waves = 1.0;
+    const double cost = waves * cfgs[i].bm * cfgs[i].bn * cfgs[i].eff;
+    if (cost < best_cost) { best_cost = cost; best = i; }
+  }
+  const int BMs = cfgs[best].bm, BNs = cfgs[best].bn;
+  a.tiles_n = (d->Cout + BNs - 1) / BNs;
+  const long nb = ((Ml + BMs - 1) / BMs) * a.tiles_n;
+  MSPI_REQUIRE(nb < (1L << 31), "mspi_conv_fwd: grid too large");
+  a.nblocks = (int)nb;
+  hipStream_t s = (hipStream_t)stream;
+  switch (best) {
+    case 0: launch_cfg<128, 128, 2, 2>(a, v4, s); break;
+    case 1: launch_cfg<128, 64, 2, 2>(a, v4, s); break;
+    case 2: launch_cfg<128, 32, 4, 1>(a, v4, s); break;
+    default: launch_cfg<64, 64, 2, 2>(a, v4, s); break;
+  }
+  return check_launch("mspi_conv_fwd");
+}

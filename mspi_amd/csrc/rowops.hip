@@ -1,0 +1,308 @@
+// Row-wise and element-wise HBM-bound kernels: LayerNorm (one wavefront per row),
+// squeeze-excite gate, bilinear up-sample(+add), SA row gate, logsumexp, row mean,
+// negative cosine, add.  All fp32, 16-B vector access along the channel axis.
+#include "common.h"
+
+namespace mspi {
+
+// ------------------------------------------------------------------ LayerNorm
+// One 64-lane wavefront per row; the row stays in registers (<= 12 float4 per lane,
+// C <= 3072) so x is read once.  Two-pass mean/variance like ATen's CPU kernel.
+constexpr int LN_MAXV = 12;
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y,
+                                                        long ldy, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, long M, int C,
+                                                        int act, const float* __restrict__ table, int P) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nv = C >> 2;
+  const float* xr = x + row * ldx;
+  float4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int i = lane + 64 * j;
+    if (i < nv) {
+      v[j] = *reinterpret_cast<const float4*>(xr + i * 4);
+      s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int i = lane + 64 * j;
+    if (i < nv) {
+      const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  float* yr = y + row * ldy;
+  const float* tr = table ? table + (long)(row % P) * C : nullptr;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int i = lane + 64 * j;
+    if (i < nv) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + i * 4);
+      const float4 b = *reinterpret_cast<const float4*>(beta + i * 4);
+      float4 o;
+      o.x = act_apply((v[j].x - mean) * rstd * g.x + b.x, act);
+      o.y = act_apply((v[j].y - mean) * rstd * g.y + b.y, act);
+      o.z = act_apply((v[j].z - mean) * rstd * g.z + b.z, act);
+      o.w = act_apply((v[j].w - mean) * rstd * g.w + b.w, act);
+      if (tr) {
+        const float4 t = *reinterpret_cast<const float4*>(tr + i * 4);
+        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+      }
+      *reinterpret_cast<float4*>(yr + i * 4) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ SE gate
+// One workgroup per sample: fc1 (C->F) by wavefront-reduced dot products, ReLU, fc2, sigmoid.
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ pool, float inv_count,
+                                                      const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      float* __restrict__ gate, int C, int F) {
+  extern __shared__ float sm[];  // [C] means, [F] hidden
+  float* mean = sm;
+  float* hid = sm + C;
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) mean[c] = pool[(long)n * C + c] * inv_count;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int f = wave; f < F; f += 4) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s = fmaf(w1[(long)f * C + c], mean[c], s);
+    s = wave_sum(s);
+    if (lane == 0) hid[f] = fmaxf(s + b1[f], 0.f);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = b2[c];
+    for (int f = 0; f < F; ++f) s = fmaf(w2[(long)c * F + f], hid[f], s);
+    gate[(long)n * C + c] = 1.f / (1.f + __expf(-s));
+  }
+}
+
+// ------------------------------------------------------------------ bilinear up-sample (+ add)
+// PyTorch align_corners=False: src = max(0, (dst + 0.5)/k - 0.5); i1 = min(i0 + 1, in - 1).
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst,
+                                                       long ldd, int NT, int H, int W, int CV, int k, int accumulate) {
+  const int Ho = H * k, Wo = W * k;
+  const long total = (long)NT * Ho * Wo * CV;
+  const float inv = 1.f / (float)k;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int cv = (int)(idx % CV);
+    long pos = idx / CV;
+    const int wo = (int)(pos % Wo);
+    pos /= Wo;
+    const int ho = (int)(pos % Ho);
+    const long nt = pos / Ho;
+    float fh = ((float)ho + 0.5f) * inv - 0.5f;
+    float fw = ((float)wo + 0.5f) * inv - 0.5f;
+    fh = fh < 0.f ? 0.f : fh;
+    fw = fw < 0.f ? 0.f : fw;
+    const int h0 = (int)fh, w0 = (int)fw;
+    const int h1 = h0 + (h0 < H - 1 ? 1 : 0), w1 = w0 + (w0 < W - 1 ? 1 : 0);
+    const float lh = fh - (float)h0, lw = fw - (float)w0;
+    const float* b = src + (nt * H * W) * lds + cv * 4;
+    const float4 v00 = *reinterpret_cast<const float4*>(b + ((long)h0 * W + w0) * lds);
+    const float4 v01 = *reinterpret_cast<const float4*>(b + ((long)h0 * W + w1) * lds);
+    const float4 v10 = *reinterpret_cast<const float4*>(b + ((long)h1 * W + w0) * lds);
+    const float4 v11 = *reinterpret_cast<const float4*>(b + ((long)h1 * W + w1) * lds);
+    const float c00 = (1.f - lh) * (1.f - lw), c01 = (1.f - lh) * lw, c10 = lh * (1.f - lw), c11 = lh * lw;
+    float4 o;
+    o.x = c00 * v00.x + c01 * v01.x + c10 * v10.x + c11 * v11.x;
+    o.y = c00 * v00.y + c01 * v01.y + c10 * v10.y + c11 * v11.y;
+    o.z = c00 * v00.z + c01 * v01.z + c10 * v10.z + c11 * v11.z;
+    o.w = c00 * v00.w + c01 * v01.w + c10 * v10.w + c11 * v11.w;
+    float* d = dst + ((nt * Ho + ho) * Wo + wo) * ldd + cv * 4;
+    if (accumulate) {
+      const float4 p = *reinterpret_cast<const float4*>(d);
+      o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+    }
+    *reinterpret_cast<float4*>(d) = o;
+  }
+}
+
+// ------------------------------------------------------------------ SA gate  x *= (1 + mask[row])
+__global__ __launch_bounds__(256) void rowgate_kernel(float* __restrict__ x, long ldx, const float* __restrict__ mask,
+                                                      long M, int CV) {
+  const long total = M * CV;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long row = idx / CV;
+    const int cv = (int)(idx - row * CV);
+    const float g = 1.f + mask[row];
+    float4* p = reinterpret_cast<float4*>(x + row * ldx + cv * 4);
+    float4 v = *p;
+    v.x *= g; v.y *= g; v.z *= g; v.w *= g;
+    *p = v;
+  }
+}
+
+// ------------------------------------------------------------------ block reductions
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < nw; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+  return r;
+}
+
+// x[n,:] -= logsumexp(x[n,:]); one 1024-thread workgroup per sample (L = H*W = 50k floats, L2 resident)
+__global__ __launch_bounds__(1024) void logsumexp_sub_kernel(float* __restrict__ x, int L) {
+  __shared__ float red[16];
+  float* xr = x + (long)blockIdx.x * L;
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < L; i += 1024) m = fmaxf(m, xr[i]);
+  m = block_reduce(m, red, true);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < L; i += 1024) s += expf(xr[i] - m);
+  s = block_reduce(s, red, false);
+  const float lse = m + logf(s);
+  for (int i = threadIdx.x; i < L; i += 1024) xr[i] -= lse;
+}
+
+// out[n,c] = mean_r x[n,r,c]; grid (ceil(C/64), N), 256 threads = 64 channels x 4 row groups
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ x, long ldx, long sample_stride,
+                                                        float* __restrict__ out, int R, int C) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  const int n = blockIdx.y;
+  float s = 0.f;
+  if (c < C) {
+    const float* b = x + (long)n * sample_stride + c;
+    for (int r = g; r < R; r += 4) s += b[(long)r * ldx];
+  }
+  part[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0 && c < C) out[(long)n * C + c] = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) / (float)R;
+}
+
+// out (+)= scale * mean_n( -cos(p_n, z_n) ), F.cosine_similarity eps = 1e-8 on each norm
+__global__ __launch_bounds__(256) void neg_cosine_kernel(const float* __restrict__ p, const float* __restrict__ z,
+                                                         float* __restrict__ out, int N, int C, float scale,
+                                                         int accumulate) {
+  __shared__ float red[4];
+  float total = 0.f;
+  for (int n = 0; n < N; ++n) {
+    float dot = 0.f, pp = 0.f, zz = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float a = p[(long)n * C + c], b = z[(long)n * C + c];
+      dot = fmaf(a, b, dot);
+      pp = fmaf(a, a, pp);
+      zz = fmaf(b, b, zz);
+    }
+    dot = block_reduce(dot, red, false);
+    pp = block_reduce(pp, red, false);
+    zz = block_reduce(zz, red, false);
+    total += dot / (fmaxf(sqrtf(pp), 1e-8f) * fmaxf(sqrtf(zz), 1e-8f));
+  }
+  if (threadIdx.x == 0) {
+    const float v = -scale * total / (float)N;
+    out[0] = accumulate ? out[0] + v : v;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ y, long n4, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+    reinterpret_cast<float4*>(y)[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+  }
+  if (blockIdx.x == 0) {
+    const long i = n4 * 4 + threadIdx.x;
+    if (i < n) y[i] = a[i] + b[i];
+  }
+}
+
+static inline unsigned grid_for(long total) {
+  long g = (total + 255) / 256;
+  const long cap = 256L * 16;  // 256 CUs x 16 resident 256-thread workgroups, grid-stride beyond that
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace mspi
+
+using namespace mspi;
+
+extern "C" int mspi_layernorm_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma,
+                                  const float* beta, float eps, int64_t M, int32_t C, int32_t act, const float* table,
+                                  int32_t P, mspi_stream_t stream) {
+  MSPI_REQUIRE(x && y && gamma && beta, "mspi_layernorm_fwd: null argument");
+  MSPI_REQUIRE(M > 0 && C > 0 && (C & 3) == 0 && C <= LN_MAXV * 256, "mspi_layernorm_fwd: C=%d must be a multiple of 4, <= %d",
+               C, LN_MAXV * 256);
+  MSPI_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C, "mspi_layernorm_fwd: bad row stride");
+  MSPI_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && (!table || (aligned16(table) && P > 0)),
+               "mspi_layernorm_fwd: pointers must be 16-B aligned");
+  MSPI_REQUIRE((M + 3) / 4 < (1L << 31), "mspi_layernorm_fwd: too many rows");
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, y,
+                     (long)ldy, gamma, beta, eps, (long)M, C, act, table, P);
+  return check_launch("mspi_layernorm_fwd");
+}
+
+extern "C" int mspi_se_gate(const float* pool, float inv_count, const float* w1, const float* b1, const float* w2,
+                            const float* b2, float* gate, int32_t N, int32_t C, int32_t F, mspi_stream_t stream) {
+  MSPI_REQUIRE(pool && w1 && b1 && w2 && b2 && gate, "mspi_se_gate: null argument");
+  MSPI_REQUIRE(N > 0 && C > 0 && F > 0 && (size_t)(C + F) * 4 <= 64 * 1024, "mspi_se_gate: bad extent");
+  hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), (size_t)(C + F) * sizeof(float), (hipStream_t)stream, pool,
+                     inv_count, w1, b1, w2, b2, gate, C, F);
+  return check_launch("mspi_se_gate");
+}
+
+extern "C" int mspi_upsample_fwd(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t NT, int32_t H,
+                                 int32_t W, int32_t C, int32_t factor, int32_t accumulate, mspi_stream_t stream) {
+  MSPI_REQUIRE(src && dst, "mspi_upsample_fwd: null argument");
+  MSPI_REQUIRE(NT > 0 && H > 0 && W > 0 && C > 0 && factor >= 1, "mspi_upsample_fwd: bad extent");
+  MSPI_REQUIRE((C & 3) == 0 && (lds & 3) == 0 && (ldd & 3) == 0 && lds >= C && ldd >= C && aligned16(src) && aligned16(dst),
+               "mspi_upsample_fwd: C/ld must be multiples of 4, pointers 16-B aligned");
+  const long total = (long)NT * H * factor * W * factor * (C / 4);
+  hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, (long)lds, dst,
+                     (long)ldd, NT, H, W, C / 4, factor, accumulate);
+  return check_launch("mspi_upsample_fwd");
+}
+
+extern "C" int mspi_rowgate(float* x, int64_t ldx, const float* mask, int64_t M, int32_t C, mspi_stream_t stream) {
+  MSPI_REQUIRE(x && mask && M > 0 && C > 0, "mspi_rowgate: bad argument");
+  MSPI_REQUIRE((C & 3) == 0 && (ldx & 3) == 0 && ldx >= C && aligned16(x), "mspi_rowgate: C/ldx must be multiples of 4");
+  hipLaunchKernelGGL(rowgate_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, mask,
+                     (long)M, C / 4);
+  return check_launch("mspi_rowgate");
+}
+
+extern "C" int mspi_logsumexp_sub(float* x, int32_t N, int32_t L, mspi_stream_t stream) {
+  MSPI_REQUIRE(x && N > 0 && L > 0, "mspi_logsumexp_sub: bad argument");
+  hipLaunchKernelGGL(logsumexp_sub_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, x, L);
+  return check_launch("mspi_logsumexp_sub");
+}
+
+extern "C" int mspi_mean_rows(const float* x, int64_t ldx, int64_t sample_stride, float* out, int32_t N, int32_t R,
+                              int32_t C, mspi_stream_t stream) {
+  MSPI_REQUIRE(x && out && N > 0 && R > 0 && C > 0 && N < 65536, "mspi_mean_rows: bad argument");
+  hipLaunchKernelGGL(mean_rows_kernel, dim3((C + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
+                     (long)sample_stride, out, R, C);
+  return check_launch("mspi_mean_rows");
+}
+
+extern "C" int mspi_neg_cosine(const float* p, const float* z, float* out, int32_t N, int32_t C, float scale,
+                               int32_t accumulate, mspi_stream_t stream) {
+  MSPI_REQUIRE(p && z && out && N > 0 && C > 0, "mspi_neg_cosine: bad argument");
+  hipLaunchKernelGGL(neg_cosine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, z, out, N, C, scale, accumulate);
+  return check_launch("mspi_neg_cosine");
+}
+
+extern "C" int mspi_add(const float* a, const float* b, float* y, int64_t n, mspi_stream_t stream) {
+  MSPI_REQUIRE(a && b && y && n > 0, "mspi_add: bad argument");
+  MSPI_REQUIRE(aligned16(a) && aligned16(b) && aligned16(y), "mspi_add: pointers must be 16-B aligned");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long)(n / 4), (long)n);
+  return check_launch("mspi_add");
+}
