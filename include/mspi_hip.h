@@ -109,14 +109,17 @@ int mspi_se_gate(const float* pool, float inv_count, const float* w1, const floa
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the C columns of each row, one wavefront per row:
- *   y[m,:] = act( (x[m,:]-mean)/sqrt(var+eps) * gamma + beta ) + table[m % P, :]
+ *   y[n,r,:] = act( (x[n,r,:]-mean)/sqrt(var+eps) * gamma + beta ) + table[r, :]
+ * Rows are addressed as base + n*sN + r*ld for n < N, r < R on both sides, so a producer can
+ * write token slabs of a [N, R_total, C] sequence buffer (the torch.cat at
+ * model/model_utils.py:277 disappears).  table (optional) has R rows.
  * Replaces nn.LayerNorm at model/model_utils.py:231-233 (+ sinusoid table add :273-274),
  *   :139,145 (Block), :296 (LayerNorm3d), :404-435 (projector LN+ReLU);
  *   backbones/MViT.py:1714; backbones/video_swin_transformer.py:306; timm LayerNorm2d.
  * ------------------------------------------------------------------------------------ */
-int mspi_layernorm_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma,
-                       const float* beta, float eps, int64_t M, int32_t C, int32_t act,
-                       const float* table /*NULL or [P][C]*/, int32_t P, mspi_stream_t stream);
+int mspi_layernorm_fwd(const float* x, int64_t ldx, int64_t sNx, float* y, int64_t ldy, int64_t sNy,
+                       const float* gamma, const float* beta, float eps, int32_t N, int32_t R, int32_t C,
+                       int32_t act, const float* table /*NULL or [R][C]*/, mspi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused multi-head attention (flash style, MFMA, online softmax, fp32):
@@ -147,11 +150,12 @@ int mspi_maxpool_fwd(const MspiDwConvDesc* d, const float* x, float* y, mspi_str
 /* ------------------------------------------------------------------------------------
  * Bilinear spatial up-sampling by an integer factor (align_corners=False; T untouched,
  * which is what trilinear with scale (1,k,k) computes), optionally accumulating:
- *   dst[n,t,ho,wo,:] (+)= bilinear(src[n,t,:,:,:])
+ *   dst[n,t,ho,wo,:] = act( (dst[n,t,ho,wo,:] +) bilinear(src[n,t,:,:,:]) )
  * Replaces nn.Upsample at model/model_utils.py:158,208,486-488,498 and the adds at :566-570.
  * ------------------------------------------------------------------------------------ */
 int mspi_upsample_fwd(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t NT, int32_t H,
-                      int32_t W, int32_t C, int32_t factor, int32_t accumulate, mspi_stream_t stream);
+                      int32_t W, int32_t C, int32_t factor, int32_t accumulate, int32_t act,
+                      mspi_stream_t stream);
 
 /* SA gating x*m + x (model/model_utils.py:167-170): x[m,:] *= (1 + mask[m]), in place. */
 int mspi_rowgate(float* x, int64_t ldx, const float* mask, int64_t M, int32_t C, mspi_stream_t stream);

@@ -1,0 +1,106 @@
+"""ctypes binding of libmspi_hip.so (C ABI declared in include/mspi_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a kernel launch fails the
+call raises.  `build()` (mspi_amd/build.py) compiles the library in-tree with hipcc.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmspi_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_SWISH = range(5)
+
+
+class MspiError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+        ("sN", C.c_int64), ("sT", C.c_int64), ("sH", C.c_int64), ("sW", C.c_int64), ("sC", C.c_int64),
+        ("kT", C.c_int32), ("kH", C.c_int32), ("kW", C.c_int32),
+        ("strT", C.c_int32), ("strH", C.c_int32), ("strW", C.c_int32),
+        ("padT", C.c_int32), ("padH", C.c_int32), ("padW", C.c_int32),
+        ("To", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("Cout", C.c_int32),
+        ("ldy", C.c_int64), ("ldw", C.c_int64), ("ldr", C.c_int64),
+        ("act", C.c_int32),
+    ]
+
+
+class DwConvDesc(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+        ("ldx", C.c_int64), ("ldy", C.c_int64),
+        ("kT", C.c_int32), ("kH", C.c_int32), ("kW", C.c_int32),
+        ("strT", C.c_int32), ("strH", C.c_int32), ("strW", C.c_int32),
+        ("padT", C.c_int32), ("padH", C.c_int32), ("padW", C.c_int32),
+        ("To", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("act", C.c_int32),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("Hh", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("D", C.c_int32),
+        ("q_sB", C.c_int64), ("q_sH", C.c_int64), ("q_sT", C.c_int64),
+        ("k_sB", C.c_int64), ("k_sH", C.c_int64), ("k_sT", C.c_int64),
+        ("v_sB", C.c_int64), ("v_sH", C.c_int64), ("v_sT", C.c_int64),
+        ("o_sB", C.c_int64), ("o_sH", C.c_int64), ("o_sT", C.c_int64),
+        ("scale", C.c_float),
+    ]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "mspi_version": (C.c_int, []),
+    "mspi_last_error": (C.c_char_p, []),
+    "mspi_device_count": (C.c_int, []),
+    "mspi_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "mspi_dwconv_fwd": (C.c_int, [C.POINTER(DwConvDesc), _P, _P, _P, _P, _P, _P]),
+    "mspi_se_gate": (C.c_int, [_P, C.c_float, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "mspi_layernorm_fwd": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P, _P, C.c_float, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "mspi_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
+    "mspi_maxpool_fwd": (C.c_int, [C.POINTER(DwConvDesc), _P, _P, _P]),
+    "mspi_upsample_fwd": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_int32, _P]),
+    "mspi_rowgate": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, _P]),
+    "mspi_logsumexp_sub": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "mspi_mean_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "mspi_neg_cosine": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P]),
+    "mspi_add": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load libmspi_hip.so; raises MspiError (never falls back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MspiError(
+            "libmspi_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(mspi_amd has no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mspi_version() != 1:
+        raise MspiError("libmspi_hip.so ABI version %d != 1" % lib.mspi_version())
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mspi_last_error().decode("utf-8", "replace")
+        raise MspiError("%s failed (%d): %s" % (what, rc, msg))

@@ -10,15 +10,18 @@ namespace mspi {
 // C <= 3072) so x is read once.  Two-pass mean/variance like ATen's CPU kernel.
 constexpr int LN_MAXV = 12;
 
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y,
-                                                        long ldy, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float eps, long M, int C,
-                                                        int act, const float* __restrict__ table, int P) {
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx, long sNx,
+                                                        float* __restrict__ y, long ldy, long sNy,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, long M, int R, int C,
+                                                        int act, const float* __restrict__ table) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  const long n = row / R;
+  const int r = (int)(row - n * R);
   const int nv = C >> 2;
-  const float* xr = x + row * ldx;
+  const float* xr = x + n * sNx + (long)r * ldx;
   float4 v[LN_MAXV];
   float s = 0.f;
 #pragma unroll
@@ -40,8 +43,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-  float* yr = y + row * ldy;
-  const float* tr = table ? table + (long)(row % P) * C : nullptr;
+  float* yr = y + n * sNy + (long)r * ldy;
+  const float* tr = table ? table + (long)r * C : nullptr;
 #pragma unroll
   for (int j = 0; j < LN_MAXV; ++j) {
     const int i = lane + 64 * j;
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
 // ------------------------------------------------------------------ bilinear up-sample (+ add)
 // PyTorch align_corners=False: src = max(0, (dst + 0.5)/k - 0.5); i1 = min(i0 + 1, in - 1).
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst,
-                                                       long ldd, int NT, int H, int W, int CV, int k, int accumulate) {
+                                                       long ldd, int NT, int H, int W, int CV, int k, int accumulate,
+                                                       int act) {
   const int Ho = H * k, Wo = W * k;
   const long total = (long)NT * Ho * Wo * CV;
   const float inv = 1.f / (float)k;
@@ -125,6 +129,9 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
     if (accumulate) {
       const float4 p = *reinterpret_cast<const float4*>(d);
       o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+    }
+    if (act != MSPI_ACT_NONE) {
+      o.x = act_apply(o.x, act); o.y = act_apply(o.y, act); o.z = act_apply(o.z, act); o.w = act_apply(o.w, act);
     }
     *reinterpret_cast<float4*>(d) = o;
   }
@@ -235,18 +242,20 @@ static inline unsigned grid_for(long total) {
 
 using namespace mspi;
 
-extern "C" int mspi_layernorm_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma,
-                                  const float* beta, float eps, int64_t M, int32_t C, int32_t act, const float* table,
-                                  int32_t P, mspi_stream_t stream) {
+extern "C" int mspi_layernorm_fwd(const float* x, int64_t ldx, int64_t sNx, float* y, int64_t ldy, int64_t sNy,
+                                  const float* gamma, const float* beta, float eps, int32_t N, int32_t R, int32_t C,
+                                  int32_t act, const float* table, mspi_stream_t stream) {
   MSPI_REQUIRE(x && y && gamma && beta, "mspi_layernorm_fwd: null argument");
-  MSPI_REQUIRE(M > 0 && C > 0 && (C & 3) == 0 && C <= LN_MAXV * 256, "mspi_layernorm_fwd: C=%d must be a multiple of 4, <= %d",
+  const int64_t M = (int64_t)N * R;
+  MSPI_REQUIRE(N > 0 && R > 0 && C > 0 && (C & 3) == 0 && C <= LN_MAXV * 256, "mspi_layernorm_fwd: C=%d must be a multiple of 4, <= %d",
                C, LN_MAXV * 256);
-  MSPI_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C, "mspi_layernorm_fwd: bad row stride");
-  MSPI_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && (!table || (aligned16(table) && P > 0)),
+  MSPI_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C && (sNx & 3) == 0 && (sNy & 3) == 0,
+               "mspi_layernorm_fwd: bad row/sample stride");
+  MSPI_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && (!table || aligned16(table)),
                "mspi_layernorm_fwd: pointers must be 16-B aligned");
   MSPI_REQUIRE((M + 3) / 4 < (1L << 31), "mspi_layernorm_fwd: too many rows");
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, y,
-                     (long)ldy, gamma, beta, eps, (long)M, C, act, table, P);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
+                     (long)sNx, y, (long)ldy, (long)sNy, gamma, beta, eps, (long)M, R, C, act, table);
   return check_launch("mspi_layernorm_fwd");
 }
 
@@ -260,14 +269,15 @@ extern "C" int mspi_se_gate(const float* pool, float inv_count, const float* w1,
 }
 
 extern "C" int mspi_upsample_fwd(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t NT, int32_t H,
-                                 int32_t W, int32_t C, int32_t factor, int32_t accumulate, mspi_stream_t stream) {
+                                 int32_t W, int32_t C, int32_t factor, int32_t accumulate, int32_t act,
+                                 mspi_stream_t stream) {
   MSPI_REQUIRE(src && dst, "mspi_upsample_fwd: null argument");
   MSPI_REQUIRE(NT > 0 && H > 0 && W > 0 && C > 0 && factor >= 1, "mspi_upsample_fwd: bad extent");
   MSPI_REQUIRE((C & 3) == 0 && (lds & 3) == 0 && (ldd & 3) == 0 && lds >= C && ldd >= C && aligned16(src) && aligned16(dst),
                "mspi_upsample_fwd: C/ld must be multiples of 4, pointers 16-B aligned");
   const long total = (long)NT * H * factor * W * factor * (C / 4);
   hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, (long)lds, dst,
-                     (long)ldd, NT, H, W, C / 4, factor, accumulate);
+                     (long)ldd, NT, H, W, C / 4, factor, accumulate, act);
   return check_launch("mspi_upsample_fwd");
 }
 

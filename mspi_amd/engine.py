@@ -1,0 +1,363 @@
+"""Host-side plumbing between the reference-shaped nn.Modules and the C ABI.
+
+* `CL`   -- a channels-last activation: M = N*T*H*W rows x C columns, row stride `ld`
+            (floats, multiple of 4) inside a flat fp32 torch buffer.  Slicing channels is free,
+            which is how concats are eliminated (producers write into their slice).
+* pack_* -- weight packing done once per parameter version: eval-mode BatchNorm folded into
+            the conv, taps made channel-minor, channel counts padded to a multiple of 4.
+* op wrappers -- conv / dwconv / layernorm / ... : fill the POD descriptor, pass raw device
+            pointers and torch's current hipStream_t.  No CPU fallback anywhere.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH, AttnDesc, ConvDesc, DwConvDesc,
+                   MspiError, check)
+
+__all__ = ["CL", "alloc", "pack_conv", "pack_dwconv", "PackedConv", "PackedDw", "conv", "dwconv", "maxpool",
+           "layernorm", "attention", "upsample", "rowgate", "logsumexp_sub", "mean_rows", "neg_cosine",
+           "se_gate", "add", "fold_bn", "ACT_NONE", "ACT_RELU", "ACT_GELU", "ACT_SIGMOID", "ACT_SWISH"]
+
+
+def rup4(c):
+    return (c + 3) // 4 * 4
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise MspiError("mspi_amd runs on the GPU only (tensor on %s); there is no CPU fallback" % t.device)
+
+
+class CL:
+    """Channels-last activation view: rows (n,t,h,w) x C stored channels, row stride ld."""
+    __slots__ = ("buf", "off", "N", "T", "H", "W", "C", "ld", "sN")
+
+    def __init__(self, buf, off, N, T, H, W, Cc, ld, sN=None):
+        self.buf, self.off, self.N, self.T, self.H, self.W, self.C, self.ld = buf, off, N, T, H, W, Cc, ld
+        self.sN = T * H * W * ld if sN is None else sN  # sample stride (floats); dense unless a token slab
+
+    @property
+    def dense(self):
+        return self.sN == self.T * self.H * self.W * self.ld
+
+    @property
+    def Cs(self):
+        """stored channels"""
+        return rup4(self.C) if self.C > 1 else 1
+
+    @property
+    def M(self):
+        return self.N * self.T * self.H * self.W
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + 4 * self.off
+
+    def slice(self, c0, c):
+        assert c0 % 4 == 0 and c0 + c <= self.ld
+        return CL(self.buf, self.off + c0, self.N, self.T, self.H, self.W, c, self.ld, self.sN)
+
+    def reshape(self, N, T, H, W):
+        assert N * T * H * W == self.M and self.dense
+        return CL(self.buf, self.off, N, T, H, W, self.C, self.ld)
+
+    def tokens(self, r0, T, H, W):
+        """Rows [r0, r0+T*H*W) of every sample as a [N,T,H,W,C] view (sample stride kept)."""
+        assert r0 + T * H * W <= self.T * self.H * self.W
+        return CL(self.buf, self.off + r0 * self.ld, self.N, T, H, W, self.C, self.ld, self.sN)
+
+    def as_ncdhw(self, channels=None):
+        """Logical [N,C,T,H,W] view (no copy) -- what the reference's modules return."""
+        c = self.C if channels is None else channels
+        ld, T, H, W = self.ld, self.T, self.H, self.W
+        return self.buf.as_strided((self.N, c, T, H, W), (self.sN, 1, H * W * ld, W * ld, ld),
+                                   self.buf.storage_offset() + self.off)
+
+    def as_rows(self, channels=None):
+        c = self.C if channels is None else channels
+        assert self.dense
+        return self.buf.as_strided((self.M, c), (self.ld, 1), self.buf.storage_offset() + self.off)
+
+
+def alloc(N, T, H, W, Cc, device, ld=None):
+    if ld is None:
+        ld = rup4(Cc) if Cc > 1 else 1
+    buf = torch.empty(N * T * H * W * ld, dtype=torch.float32, device=device)
+    return CL(buf, 0, N, T, H, W, Cc, ld)
+
+
+def from_rows(t2d):
+    """Wrap a contiguous [M, C] tensor (C % 4 == 0) as a CL with N=M, T=H=W=1."""
+    assert t2d.dim() == 2 and t2d.stride(1) == 1 and t2d.stride(0) % 4 == 0
+    return CL(t2d, 0, t2d.shape[0], 1, 1, 1, t2d.shape[1], t2d.stride(0))
+
+
+# ----------------------------------------------------------------------------- packing
+def fold_bn(weight, bias, bn):
+    """Fold an eval-mode BatchNorm (running stats) into the preceding conv: returns (w, b)."""
+    w = weight.detach().float()
+    b = None if bias is None else bias.detach().float()
+    if bn is not None:
+        s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        w = w * s.view(-1, *([1] * (w.dim() - 1)))
+        b0 = bn.bias.detach().float() - bn.running_mean.detach().float() * s
+        b = b0 if b is None else b0 + b * s
+    return w, b
+
+
+class PackedConv:
+    __slots__ = ("w", "bias", "k", "stride", "pad", "cin", "cin_s", "cout", "cout_s", "ldw", "act")
+
+
+def pack_conv(weight, bias=None, bn=None, stride=(1, 1, 1), pad=(0, 0, 0), act=ACT_NONE, cin_stored=None,
+              out_scale=None, device=None):
+    """weight: [Co,Ci] (Linear), [Co,Ci,kh,kw] (2-D) or [Co,Ci,kt,kh,kw].  Result rows are
+    [Co_s][ldw] with k = (kt,kh,kw,ci) ci fastest, Ci padded to cin_stored, Co to a multiple of 4."""
+    w, b = fold_bn(weight, bias, bn)
+    if w.dim() == 2:
+        w = w[:, :, None, None, None]
+    elif w.dim() == 4:
+        w = w[:, :, None]
+    if out_scale is not None:  # e.g. ConvNeXt layer-scale gamma folded into the producing conv
+        s = out_scale.detach().float().view(-1)
+        w = w * s.view(-1, 1, 1, 1, 1)
+        b = None if b is None else b * s
+    co, ci, kt, kh, kw = w.shape
+    cin_s = ci if cin_stored is None else cin_stored
+    assert cin_s >= ci
+    cout_s = rup4(co) if co > 1 else 1
+    K = kt * kh * kw * cin_s
+    ldw = rup4(K)
+    wp = torch.zeros(cout_s, kt, kh, kw, cin_s, dtype=torch.float32, device=w.device)
+    wp[:co, :, :, :, :ci] = w.permute(0, 2, 3, 4, 1)
+    wf = torch.zeros(cout_s, ldw, dtype=torch.float32, device=w.device)
+    wf[:, :K] = wp.reshape(cout_s, K)
+    p = PackedConv()
+    dev = w.device if device is None else device
+    p.w = wf.to(dev).contiguous()
+    if b is None:
+        p.bias = None
+    else:
+        bp = torch.zeros(cout_s, dtype=torch.float32, device=w.device)
+        bp[:co] = b
+        p.bias = bp.to(dev)
+    p.k, p.stride, p.pad = (kt, kh, kw), tuple(stride), tuple(pad)
+    p.cin, p.cin_s, p.cout, p.cout_s, p.ldw, p.act = ci, cin_s, co, cout_s, ldw, act
+    return p
+
+
+class PackedDw:
+    __slots__ = ("w", "bias", "k", "stride", "pad", "c", "c_s", "act")
+
+
+def pack_dwconv(weight, bias=None, bn=None, stride=(1, 1, 1), pad=(0, 0, 0), act=ACT_NONE, device=None):
+    """weight: [C,1,kt,kh,kw] or [C,1,kh,kw] depthwise.  Packed as [taps][C_s]."""
+    w, b = fold_bn(weight, bias, bn)
+    if w.dim() == 4:
+        w = w[:, :, None]
+    c, one, kt, kh, kw = w.shape
+    assert one == 1
+    c_s = rup4(c)
+    wp = torch.zeros(kt * kh * kw, c_s, dtype=torch.float32, device=w.device)
+    wp[:, :c] = w.reshape(c, kt * kh * kw).t()
+    bp = torch.zeros(c_s, dtype=torch.float32, device=w.device)
+    if b is not None:
+        bp[:c] = b
+    p = PackedDw()
+    dev = w.device if device is None else device
+    p.w, p.bias = wp.to(dev).contiguous(), bp.to(dev)
+    p.k, p.stride, p.pad, p.c, p.c_s, p.act = (kt, kh, kw), tuple(stride), tuple(pad), c, c_s, act
+    return p
+
+
+def _pad_vec(v, n):
+    out = torch.zeros(n, dtype=torch.float32, device=v.device)
+    out[: v.numel()] = v.detach().float().view(-1)
+    return out
+
+
+# ----------------------------------------------------------------------------- op wrappers
+def _out_extent(T, H, W, k, s, p):
+    return ((T + 2 * p[0] - k[0]) // s[0] + 1, (H + 2 * p[1] - k[1]) // s[1] + 1, (W + 2 * p[2] - k[2]) // s[2] + 1)
+
+
+def conv(x, pk, out=None, res=None, gate=None, act=None):
+    """x: CL, or a raw 5-D [N,C,T,H,W] / 4-D [N,C,H,W] torch tensor with arbitrary strides."""
+    lib = _lib.load()
+    d = ConvDesc()
+    if isinstance(x, CL):
+        _need_gpu(x.buf)
+        N, T, H, W, Cin = x.N, x.T, x.H, x.W, x.Cs
+        d.sN, d.sT, d.sH, d.sW, d.sC = x.sN, H * W * x.ld, W * x.ld, x.ld, 1
+        xptr, dev = x.ptr, x.buf.device
+    else:
+        _need_gpu(x)
+        if x.dim() == 4:
+            x = x[:, :, None]
+        if x.dtype != torch.float32:
+            raise MspiError("conv: input must be fp32")
+        N, Cin, T, H, W = x.shape
+        sN, sC, sT, sH, sW = x.stride()
+        d.sN, d.sT, d.sH, d.sW, d.sC = sN, sT, sH, sW, sC
+        xptr, dev = x.data_ptr(), x.device
+    if Cin != pk.cin_s:
+        raise MspiError("conv: input has %d stored channels, weights were packed for %d" % (Cin, pk.cin_s))
+    To, Ho, Wo = _out_extent(T, H, W, pk.k, pk.stride, pk.pad)
+    if out is None:
+        out = alloc(N, To, Ho, Wo, pk.cout, dev)
+    if (out.N, out.T, out.H, out.W) != (N, To, Ho, Wo) or out.Cs != pk.cout_s or not out.dense:
+        raise MspiError("conv: output CL %s does not match %s" % ((out.N, out.T, out.H, out.W, out.C), (N, To, Ho, Wo, pk.cout)))
+    d.N, d.T, d.H, d.W, d.C = N, T, H, W, Cin
+    d.kT, d.kH, d.kW = pk.k
+    d.strT, d.strH, d.strW = pk.stride
+    d.padT, d.padH, d.padW = pk.pad
+    d.To, d.Ho, d.Wo = To, Ho, Wo
+    d.Cout = pk.cout_s
+    d.ldy, d.ldw = out.ld, pk.ldw
+    d.ldr = res.ld if res is not None else 0
+    d.act = pk.act if act is None else act
+    if res is not None and (res.M != out.M or not res.dense):
+        raise MspiError("conv: residual rows %d != output rows %d (or residual not dense)" % (res.M, out.M))
+    check(lib.mspi_conv_fwd(C.byref(d), xptr, pk.w.data_ptr(), pk.bias.data_ptr() if pk.bias is not None else None,
+                            res.ptr if res is not None else None, gate.data_ptr() if gate is not None else None,
+                            out.ptr, _stream()), "mspi_conv_fwd")
+    return out
+
+
+def _dw_desc(x, k, s, p, out_ld):
+    d = DwConvDesc()
+    assert x.dense
+    d.N, d.T, d.H, d.W, d.C = x.N, x.T, x.H, x.W, x.Cs
+    d.ldx, d.ldy = x.ld, out_ld
+    d.kT, d.kH, d.kW = k
+    d.strT, d.strH, d.strW = s
+    d.padT, d.padH, d.padW = p
+    d.To, d.Ho, d.Wo = _out_extent(x.T, x.H, x.W, k, s, p)
+    return d
+
+
+def dwconv(x, pk, out=None, pool=None, act=None):
+    lib = _lib.load()
+    _need_gpu(x.buf)
+    if x.Cs != pk.c_s:
+        raise MspiError("dwconv: input has %d channels, weights packed for %d" % (x.C, pk.c_s))
+    To, Ho, Wo = _out_extent(x.T, x.H, x.W, pk.k, pk.stride, pk.pad)
+    if out is None:
+        out = alloc(x.N, To, Ho, Wo, x.C, x.buf.device)
+    d = _dw_desc(x, pk.k, pk.stride, pk.pad, out.ld)
+    d.act = pk.act if act is None else act
+    check(lib.mspi_dwconv_fwd(C.byref(d), x.ptr, pk.w.data_ptr(), pk.bias.data_ptr(), out.ptr,
+                              pool.data_ptr() if pool is not None else None, _stream()), "mspi_dwconv_fwd")
+    return out
+
+
+def maxpool(x, k, s, p, out=None):
+    lib = _lib.load()
+    _need_gpu(x.buf)
+    To, Ho, Wo = _out_extent(x.T, x.H, x.W, k, s, p)
+    if out is None:
+        out = alloc(x.N, To, Ho, Wo, x.C, x.buf.device)
+    d = _dw_desc(x, k, s, p, out.ld)
+    d.act = ACT_NONE
+    check(lib.mspi_maxpool_fwd(C.byref(d), x.ptr, out.ptr, _stream()), "mspi_maxpool_fwd")
+    return out
+
+
+def se_gate(pool, inv_count, w1, b1, w2, b2, gate):
+    lib = _lib.load()
+    N, Cc = pool.shape
+    check(lib.mspi_se_gate(pool.data_ptr(), float(inv_count), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                           b2.data_ptr(), gate.data_ptr(), N, Cc, w1.shape[0], _stream()), "mspi_se_gate")
+    return gate
+
+
+def layernorm(x, gamma, beta, eps, out=None, act=ACT_NONE, table=None):
+    """Rows of x -> rows of out; x and out may be token slabs (sample stride != dense)."""
+    lib = _lib.load()
+    _need_gpu(x.buf)
+    if out is None:
+        out = alloc(x.N, x.T, x.H, x.W, x.C, x.buf.device)
+    R = x.T * x.H * x.W
+    assert out.N == x.N and out.T * out.H * out.W == R and out.C == x.C
+    P = 0 if table is None else table.shape[0]
+    assert table is None or P == R
+    check(lib.mspi_layernorm_fwd(x.ptr, x.ld, x.sN, out.ptr, out.ld, out.sN, gamma.data_ptr(), beta.data_ptr(),
+                                 float(eps), x.N, R, x.C, act, table.data_ptr() if table is not None else None,
+                                 _stream()), "mspi_layernorm_fwd")
+    return out
+
+
+def attention(qkv, B, Ntok, heads, hd, scale, out=None):
+    """qkv: CL with rows (b, token) and 3*heads*hd columns laid out [3][heads][hd]
+    (what `qkv.reshape(B,N,3,h,hd)` means, model/model_utils.py:100)."""
+    lib = _lib.load()
+    Cc = heads * hd
+    assert qkv.C == 3 * Cc and qkv.M == B * Ntok
+    if out is None:
+        out = alloc(qkv.N, qkv.T, qkv.H, qkv.W, Cc, qkv.buf.device)
+    d = AttnDesc()
+    d.B, d.Hh, d.Nq, d.Nk, d.D = B, heads, Ntok, Ntok, hd
+    d.q_sB = d.k_sB = d.v_sB = Ntok * qkv.ld
+    d.q_sH = d.k_sH = d.v_sH = hd
+    d.q_sT = d.k_sT = d.v_sT = qkv.ld
+    d.o_sB, d.o_sH, d.o_sT = Ntok * out.ld, hd, out.ld
+    d.scale = float(scale)
+    base = qkv.ptr
+    check(lib.mspi_attn_fwd(C.byref(d), base, base + 4 * Cc, base + 8 * Cc, out.ptr, _stream()), "mspi_attn_fwd")
+    return out
+
+
+def upsample(src, factor, dst=None, accumulate=False, act=ACT_NONE):
+    lib = _lib.load()
+    assert src.dense
+    if dst is None:
+        assert not accumulate
+        dst = alloc(src.N, src.T, src.H * factor, src.W * factor, src.C, src.buf.device)
+    assert (dst.N, dst.T, dst.H, dst.W) == (src.N, src.T, src.H * factor, src.W * factor) and dst.C == src.C
+    assert dst.dense
+    check(lib.mspi_upsample_fwd(src.ptr, src.ld, dst.ptr, dst.ld, src.N * src.T, src.H, src.W, src.Cs, factor,
+                                1 if accumulate else 0, act, _stream()), "mspi_upsample_fwd")
+    return dst
+
+
+def rowgate(x, mask):
+    lib = _lib.load()
+    assert mask.M == x.M and mask.ld == 1
+    assert x.dense and mask.dense
+    check(lib.mspi_rowgate(x.ptr, x.ld, mask.ptr, x.M, x.Cs, _stream()), "mspi_rowgate")
+    return x
+
+
+def logsumexp_sub(t, N, L):
+    lib = _lib.load()
+    check(lib.mspi_logsumexp_sub(t.data_ptr(), N, L, _stream()), "mspi_logsumexp_sub")
+    return t
+
+
+def mean_rows(x, N, R, out):
+    """x: CL with R = T*H*W rows per sample (token slabs allowed); out [N, C] tensor."""
+    lib = _lib.load()
+    assert x.N == N and x.T * x.H * x.W == R
+    check(lib.mspi_mean_rows(x.ptr, x.ld, x.sN, out.data_ptr(), N, R, x.C, _stream()), "mspi_mean_rows")
+    return out
+
+
+def neg_cosine(p, z, out, scale, accumulate):
+    lib = _lib.load()
+    assert p.ld == p.C and z.ld == z.C and p.dense and z.dense
+    check(lib.mspi_neg_cosine(p.ptr, z.ptr, out.data_ptr(), p.M, p.C, float(scale), 1 if accumulate else 0, _stream()),
+          "mspi_neg_cosine")
+    return out
+
+
+def add(a, b, y):
+    lib = _lib.load()
+    check(lib.mspi_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "mspi_add")
+    return y

@@ -1,0 +1,180 @@
+"""Golden-vector generator (runs ONLY in the build container, where /root/reference exists).
+
+For each case: build the *product* module tree (mspi_amd, parameter holders with the
+reference's key names) under a seed, load its state dict with strict=True into the
+*reference* module imported from /root/reference (which also proves key/shape parity), run
+the reference CPU fp32 forward on seeded inputs and store the outputs under tests/golden/.
+Weights and inputs are reproducible from seeds (mspi_amd.testing), so only outputs, seeds and
+a state-dict checksum are committed.
+
+ConvNeXt-Tiny: timm is absent, so the reference's `timm.create_model` call is routed to a
+module that runs oracle.restate.convnext_tiny_features (PARITY UNPINNED for that sub-network;
+everything downstream of it in the reference's forward runs unmodified).
+
+Usage: python oracle/gen_golden.py [case ...]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from mspi_amd import testing as T  # noqa: E402
+from oracle import ref_harness as rh  # noqa: E402
+from oracle import restate as R  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+class _RefConvNeXt(nn.Module):
+    """Stand-in for timm's FeatureListNet inside the reference model: parameters named like timm's,
+    arithmetic = the oracle's restatement."""
+
+    def __init__(self):
+        super().__init__()
+        from mspi_amd.backbones.convnext import ConvNeXtTinyFeatures
+        holder = ConvNeXtTinyFeatures()
+        for n, c in holder.named_children():
+            self.add_module(n, c)
+
+    def forward(self, x):
+        return R.convnext_tiny_features(self.state_dict(), x)
+
+
+class _NoWeights(dict):
+    def __getitem__(self, k):
+        return _NoWeights()
+
+
+def build_reference_model(name, cls_name, num_vis_tokens=None):
+    """Construct the reference AudioVisualSaliencyModel / VisualSaliencyModel offline:
+    create_model -> stand-in, the three torch.load of absent weight files -> no-ops."""
+    cfg = rh.with_config(name)
+    if num_vis_tokens is not None:
+        cfg.MODEL.NUM_VIS_TOKENS[name] = num_vis_tokens
+    rh.set_create_model(lambda *a, **k: _RefConvNeXt())
+    import model.model_utils as mu
+    real_load, real_lsd = torch.load, nn.Module.load_state_dict
+    torch.load = lambda *a, **k: _NoWeights()
+    nn.Module.load_state_dict = lambda self, sd, *a, **k: None if isinstance(sd, _NoWeights) else real_lsd(self, sd, *a, **k)
+    try:
+        m = getattr(mu, cls_name)(cfg)
+    finally:
+        torch.load, nn.Module.load_state_dict = real_load, real_lsd
+    return m.eval()
+
+
+def _save(case, **arrs):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, case + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print("  wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def _check_restatement(name, ref_out, ora_out, tol=2e-5):
+    err = max((a - b).abs().max().item() for a, b in zip(ref_out, ora_out))
+    print("  %s: max |reference - oracle| = %.3e" % (name, err))
+    assert err < tol, "oracle restatement drifted from the reference"
+
+
+# ------------------------------------------------------------------------------- cases
+def case_sinusoid():
+    rh.enter_reference()
+    import model.model_utils as mu
+    ref = mu.get_sinusoid_encoding_table(90, 512)[0]
+    _check_restatement("sinusoid", [ref], [R.sinusoid_table(90, 512)], 1e-7)
+    _save("sinusoid_90x512", table=ref)
+
+
+def case_x3dl_backbone(size=64, seed=0):
+    from mspi_amd.backbones.X3D import X3D
+    from mspi_amd.config import cfg as pcfg
+    prod = T.seeded(lambda: X3D(pcfg.MODEL.X3D.PATH_CFG), seed)
+    sd = prod.state_dict()
+    rcfg = rh.with_config("x3dl")
+    from backbones.X3D import X3D as RefX3D
+    ref = RefX3D(path_to_config=rcfg.MODEL.X3D.PATH_CFG).eval()
+    ref.load_state_dict(sd, strict=True)
+    clips, _ = T.synth_inputs(2, 16, size, size, seed=seed)
+    with torch.no_grad():
+        feats = ref([clips])
+        ora = R.x3d_forward(sd, clips)
+    _check_restatement("x3dl backbone", feats, ora)
+    _save("x3dl_backbone_%d" % size, seed=seed, size=size, batch=2, sd_crc=T.sd_checksum(sd),
+          **{"v%d" % (i + 1): f for i, f in enumerate(feats)})
+
+
+def case_resnet18_audio(seed=0):
+    from mspi_amd.backbones.resnet import ResNet
+    prod = T.seeded(ResNet, seed)
+    sd = prod.state_dict()
+    rh.enter_reference()
+    from backbones.resnet import get_resnet18
+    ref = get_resnet18(pretrained=False).eval()
+    ref.load_state_dict(sd, strict=True)
+    for wa in (111, 300):
+        _, audio = T.synth_inputs(2, Wa=wa, H=8, W=8, seed=seed)
+        with torch.no_grad():
+            out = ref(audio)
+            ora = R.resnet18_forward(sd, audio)
+        _check_restatement("resnet18 audio Wa=%d" % wa, [out], [ora])
+        _save("resnet18_audio_%d" % wa, seed=seed, batch=2, sd_crc=T.sd_checksum(sd), out=out)
+
+
+def _model_case(name, cls_name, size, B, wa, seed, tag):
+    from mspi_amd.model import model_utils as pm
+    t_tok = {"x3dl": 16, "slowfast4x16": 4}.get(name, 8)
+    nvt = t_tok * (size // 32) ** 2
+    aud_tok = 9 * ((wa + 31) // 32)
+    pcfg = T.make_cfg(name, num_aud_tokens=aud_tok, num_vis_tokens=nvt)
+    prod = T.seeded(lambda: getattr(pm, cls_name)(pcfg), seed)
+    sd = prod.state_dict()
+    ref = build_reference_model(name, cls_name, num_vis_tokens=nvt)
+    missing = set(ref.state_dict()) ^ set(sd)
+    assert not missing, "state-dict keys differ: %s" % sorted(missing)[:8]
+    ref.load_state_dict(sd, strict=True)
+    if cls_name == "AudioVisualSaliencyModel" and aud_tok != 36:   # F3: rebuild the plain-tensor table
+        import model.model_utils as mu
+        ref.aud_vis_sync_block.aud_pos_embed = mu.get_sinusoid_encoding_table(aud_tok, 512)
+    clips, audio = T.synth_inputs(B, 16, size, size, Wa=wa, seed=seed)
+    t0 = time.time()
+    with torch.no_grad():
+        if cls_name == "AudioVisualSaliencyModel":
+            out, loss = ref(clips, audio)
+            o2, l2 = R.audio_visual_forward(sd, clips, audio, name, pcfg.MODEL.LATERAL_BOOL, pcfg.MODEL.LATERAL_STRIDE)
+            _check_restatement("%s loss" % tag, [loss], [l2], 1e-5)
+        else:
+            out, loss = ref(clips)
+            o2, _ = R.visual_forward(sd, clips, name, pcfg.MODEL.LATERAL_BOOL, pcfg.MODEL.LATERAL_STRIDE)
+            loss = torch.zeros(())
+    print("  reference forward %.1fs; logsumexp=%.2e" % (time.time() - t0, torch.logsumexp(out[0], (0, 1)).item()))
+    _check_restatement(tag, [out], [o2], 5e-5)
+    _save(tag, seed=seed, size=size, batch=B, wa=wa, num_vis_tokens=nvt, num_aud_tokens=aud_tok,
+          sd_crc=T.sd_checksum(sd), out=out, loss=loss)
+
+
+def case_av_x3dl_64():
+    _model_case("x3dl", "AudioVisualSaliencyModel", 64, 2, 111, 0, "av_x3dl_64")
+
+
+def case_av_x3dl_224():
+    _model_case("x3dl", "AudioVisualSaliencyModel", 224, 1, 300, 0, "av_x3dl_224")
+
+
+def case_vis_x3dl_64():
+    _model_case("x3dl", "VisualSaliencyModel", 64, 2, 111, 0, "vis_x3dl_64")
+
+
+CASES = {k[5:]: v for k, v in list(globals().items()) if k.startswith("case_")}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CASES)
+    for n in names:
+        print("[golden] %s" % n)
+        CASES[n]()

@@ -1,0 +1,347 @@
+"""ORACLE -- CPU restatement of MSPI's saliency-inference path in plain torch (fp32, functional).
+
+TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; mspi_amd/ never does (the product path has no CPU
+fallback).  Every function takes a state dict `sd` (reference key names) and a key prefix and
+cites the reference lines it restates.
+
+Pinning: the reference ships no tests or golden vectors, so this
+restatement is pinned against the reference itself, imported on CPU in the build container by
+oracle/gen_golden.py; the outputs are committed under tests/golden/ and
+tests/test_oracle_golden.py checks every function here against them.  Exception: ConvNeXt-Tiny
+(`convnext_tiny_features`) restates timm==0.6.12's published architecture, which is not in the
+reference tree and not importable offline -> PARITY UNPINNED for that one function.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------- helpers
+def _bn(sd, p, x, eps):
+    """Eval-mode BatchNorm{2,3}d: running stats + affine."""
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                        False, 0.0, eps)
+
+
+def _conv3(sd, p, x, stride=1, padding=0, groups=1):
+    return F.conv3d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride, padding, 1, groups)
+
+
+def _conv2(sd, p, x, stride=1, padding=0, groups=1):
+    return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride, padding, 1, groups)
+
+
+def _lin(sd, p, x):
+    return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
+
+
+def _ln(sd, p, x, eps=1e-5):
+    w = sd[p + ".weight"]
+    return F.layer_norm(x, (w.shape[0],), w, sd[p + ".bias"], eps)
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)  # SlowFast/resnet_helper.py:76-103
+
+
+# ------------------------------------------------------------------------------- X3D
+def x3d_stem(sd, p, x):
+    """SlowFast/stem_helper.py:207-290: conv_xy -> depthwise temporal conv -> BN(1e-5) -> ReLU."""
+    k = sd[p + ".conv_xy.weight"].shape
+    x = _conv3(sd, p + ".conv_xy", x, (1, 2, 2), (0, k[3] // 2, k[4] // 2))
+    kt = sd[p + ".conv.weight"].shape[2]
+    x = _conv3(sd, p + ".conv", x, 1, (kt // 2, 0, 0), groups=x.shape[1])
+    return F.relu(_bn(sd, p + ".bn", x, 1e-5))
+
+
+def se_block(sd, p, x):
+    """SlowFast/resnet_helper.py:27-73."""
+    s = x.mean((2, 3, 4), keepdim=True)
+    s = F.relu(_conv3(sd, p + ".fc1", s))
+    s = torch.sigmoid(_conv3(sd, p + ".fc2", s))
+    return x * s
+
+
+def x3d_transform(sd, p, x, stride):
+    """SlowFast/resnet_helper.py:213-351; child order a,a_bn,a_relu,b,b_bn,[se],b_relu(Swish),c,c_bn."""
+    x = F.relu(_bn(sd, p + ".a_bn", _conv3(sd, p + ".a", x), 1e-5))
+    kt = sd[p + ".b.weight"].shape[2]
+    x = _bn(sd, p + ".b_bn", _conv3(sd, p + ".b", x, (1, stride, stride), (kt // 2, 1, 1), groups=x.shape[1]), 1e-5)
+    if p + ".se.fc1.weight" in sd:
+        x = se_block(sd, p + ".se", x)
+    x = _swish(x)
+    return _bn(sd, p + ".c_bn", _conv3(sd, p + ".c", x), 1e-5)
+
+
+def bottleneck_transform(sd, p, x, stride):
+    """SlowFast/resnet_helper.py:354-487 (stride on the 3x3: STRIDE_1X1 False)."""
+    kt = sd[p + ".a.weight"].shape[2]
+    x = F.relu(_bn(sd, p + ".a_bn", _conv3(sd, p + ".a", x, 1, (kt // 2, 0, 0)), 1e-5))
+    x = F.relu(_bn(sd, p + ".b_bn", _conv3(sd, p + ".b", x, (1, stride, stride), (0, 1, 1)), 1e-5))
+    return _bn(sd, p + ".c_bn", _conv3(sd, p + ".c", x), 1e-5)
+
+
+def res_block(sd, p, x, stride, trans):
+    """SlowFast/resnet_helper.py:490-616 (eval: no drop-connect)."""
+    f = trans(sd, p + ".branch2", x, stride)
+    if p + ".branch1.weight" in sd:
+        x = _bn(sd, p + ".branch1_bn", _conv3(sd, p + ".branch1", x, (1, stride, stride)), 1e-5)
+    return F.relu(x + f)
+
+
+def res_stage(sd, p, x, pathway, stride, trans):
+    i = 0
+    while "%s.pathway%d_res%d.branch2.a.weight" % (p, pathway, i) in sd:
+        x = res_block(sd, "%s.pathway%d_res%d" % (p, pathway, i), x, stride if i == 0 else 1, trans)
+        i += 1
+    return x
+
+
+def x3d_forward(sd, clips, prefix=""):
+    """backbones/X3D.py:236-246: s1..s5, features = outputs of s2..s5."""
+    x = x3d_stem(sd, prefix + "s1.pathway0_stem", clips)
+    feats = []
+    for s in ("s2", "s3", "s4", "s5"):
+        x = res_stage(sd, prefix + s, x, 0, 2, x3d_transform)
+        feats.append(x)
+    return feats
+
+
+# ------------------------------------------------------------------------------- audio ResNet-18
+def resnet18_forward(sd, x, prefix=""):
+    """backbones/resnet.py:57-143 (1-channel stem, BasicBlock x [2,2,2,2], returns layer4 map)."""
+    p = prefix
+    x = F.relu(_bn(sd, p + "bn1", _conv2(sd, p + "conv1", x, 2, 3), 1e-5))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li in range(1, 5):
+        for bi in range(2):
+            q = "%slayer%d.%d" % (p, li, bi)
+            stride = 2 if (li > 1 and bi == 0) else 1
+            idt = x
+            o = F.relu(_bn(sd, q + ".bn1", _conv2(sd, q + ".conv1", x, stride, 1), 1e-5))
+            o = _bn(sd, q + ".bn2", _conv2(sd, q + ".conv2", o, 1, 1), 1e-5)
+            if q + ".downsample.0.weight" in sd:
+                idt = _bn(sd, q + ".downsample.1", _conv2(sd, q + ".downsample.0", x, stride, 0), 1e-5)
+            x = F.relu(o + idt)
+    return x
+
+
+# ------------------------------------------------------------------------------- ConvNeXt-T (timm 0.6.12) -- PARITY UNPINNED
+def convnext_tiny_features(sd, x, prefix=""):
+    """timm==0.6.12 `convnext_tiny`, features_only=True (call site model/model_utils.py:361,380).
+    Published architecture: stem conv4x4/4 + LayerNorm2d; stages depths (3,3,9,3), dims
+    (96,192,384,768); block = dw7x7 -> LN(1e-6) -> fc1 -> GELU -> fc2 -> gamma -> + shortcut;
+    downsample = LayerNorm2d + conv2x2/2.  Returns the 4 stage outputs (strides 4,8,16,32)."""
+    p = prefix
+
+    def ln2d(q, t):
+        return _ln(sd, q, t.permute(0, 2, 3, 1), 1e-6).permute(0, 3, 1, 2)
+
+    x = ln2d(p + "stem_1", _conv2(sd, p + "stem_0", x, 4, 0))
+    outs = []
+    for si, depth in enumerate((3, 3, 9, 3)):
+        sp = "%sstages_%d" % (p, si)
+        if si > 0:
+            x = _conv2(sd, sp + ".downsample.1", ln2d(sp + ".downsample.0", x), 2, 0)
+        for bi in range(depth):
+            q = "%s.blocks.%d" % (sp, bi)
+            y = _conv2(sd, q + ".conv_dw", x, 1, 3, groups=x.shape[1]).permute(0, 2, 3, 1)
+            y = _ln(sd, q + ".norm", y, 1e-6)
+            y = _lin(sd, q + ".mlp.fc2", F.gelu(_lin(sd, q + ".mlp.fc1", y)))
+            y = (y * sd[q + ".gamma"]).permute(0, 3, 1, 2)
+            x = x + y
+        outs.append(x)
+    return outs
+
+
+def static_saliency_encoder(sd, frames, prefix="image_encoder."):
+    """StaticSaliencyModelConvNext.forward, model/model_utils.py:379-385."""
+    o3, o2, o1, o0 = convnext_tiny_features(sd, frames, prefix + "encoder.")
+    p = prefix
+    o0 = F.relu(_bn(sd, p + "smooth_0.1", _conv2(sd, p + "smooth_0.0", o0, 1, 1), 1e-5))
+    o1 = F.relu(_bn(sd, p + "smooth_1.1", _conv2(sd, p + "smooth_1.0", o1, 1, 1), 1e-5))
+    return o1, o0
+
+
+# ------------------------------------------------------------------------------- head pieces
+def basic_conv3d(sd, p, x, padding):
+    """backbones/s3d.py:41-52 (BN eps 1e-3)."""
+    return F.relu(_bn(sd, p + ".bn", _conv3(sd, p + ".conv", x, 1, padding), 1e-3))
+
+
+def sep_conv3d(sd, p, x):
+    """backbones/s3d.py:95-116, kernel 3 stride 1 padding 1."""
+    x = F.relu(_bn(sd, p + ".bn_s", _conv3(sd, p + ".conv_s", x, 1, (0, 1, 1)), 1e-3))
+    return F.relu(_bn(sd, p + ".bn_t", _conv3(sd, p + ".conv_t", x, 1, (1, 0, 0)), 1e-3))
+
+
+def inception(sd, p, x):
+    """model/model_utils.py:173-199."""
+    x0 = basic_conv3d(sd, p + ".branch0.0", x, 0)
+    x1 = sep_conv3d(sd, p + ".branch1.1", basic_conv3d(sd, p + ".branch1.0", x, 0))
+    x2 = sep_conv3d(sd, p + ".branch2.1", basic_conv3d(sd, p + ".branch2.0", x, 0))
+    x3 = basic_conv3d(sd, p + ".branch3.1", F.max_pool3d(x, 3, 1, 1), 0)
+    return torch.cat((x0, x1, x2, x3), 1)
+
+
+def _up(x, k):
+    return F.interpolate(x, scale_factor=(1, k, k), mode="trilinear", align_corners=False)
+
+
+def adapter(sd, p, o3, o2, num_frames, stride):
+    """model/model_utils.py:202-220."""
+    def unfold(t):
+        bt, c, h, w = t.shape
+        return t.view(bt // num_frames, num_frames, c, h, w).permute(0, 2, 1, 3, 4)
+
+    o3_ = F.max_pool3d(unfold(o3), (stride, 1, 1), (stride, 1, 1))
+    o2_ = F.max_pool3d(unfold(o2), (stride, 1, 1), (stride, 1, 1))
+    return inception(sd, p + ".conv", torch.cat([o3_, _up(o2_, 2)], 1))
+
+
+def sa_gate(sd, p, x, mask, k):
+    """model/model_utils.py:155-170."""
+    m = basic_conv3d(sd, p + ".conv_mask.0", mask, 1)
+    if k != 1:
+        m = _up(m, k)
+    m = torch.sigmoid(_conv3(sd, p + ".conv_mask.2", m, 1, (0, 1, 1)))
+    return x * m + x
+
+
+def convnext_block3d(sd, p, x):
+    """model/model_utils.py:306-354 (LayerNorm3d :293-303, eps 1e-5)."""
+    y = _conv3(sd, p + ".dwconv_t", x, 1, (3, 0, 0), groups=x.shape[1])
+    y = _conv3(sd, p + ".dwconv_s", y, 1, (0, 3, 3), groups=x.shape[1])
+    y = _ln(sd, p + ".norm.norm", y.permute(0, 2, 3, 4, 1)).permute(0, 4, 1, 2, 3)
+    y = _conv3(sd, p + ".pwconv2", F.gelu(_conv3(sd, p + ".pwconv1", y)))
+    return x + y
+
+
+def latlayer(sd, p, x, lateral, stride):
+    """model/model_utils.py:437-484."""
+    x = _conv3(sd, p + ".0", x)
+    if lateral:
+        x = _conv3(sd, p + ".1", x, (stride, 1, 1))
+        return convnext_block3d(sd, p + ".2", x)
+    return convnext_block3d(sd, p + ".1", x)
+
+
+def sinusoid_table(n_position, d_hid):
+    """model/model_utils.py:18-29 (float64 numpy, cast to float32)."""
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)[None, :]
+    tab = pos / np.power(10000, 2 * (j // 2) / d_hid)
+    tab[:, 0::2] = np.sin(tab[:, 0::2])
+    tab[:, 1::2] = np.cos(tab[:, 1::2])
+    return torch.tensor(tab, dtype=torch.float)
+
+
+def vit_block(sd, p, x, heads):
+    """model/model_utils.py:84-152: pre-LN block, qkv without bias, no LayerScale."""
+    B, N, Cc = x.shape
+    h = _ln(sd, p + ".norm1", x)
+    qkv = _lin(sd, p + ".attn.qkv", h).reshape(B, N, 3, heads, Cc // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv.unbind(0)
+    a = ((q @ k.transpose(-2, -1)) * (Cc // heads) ** -0.5).softmax(-1)
+    x = x + _lin(sd, p + ".attn.proj", (a @ v).transpose(1, 2).reshape(B, N, Cc))
+    h = _ln(sd, p + ".norm2", x)
+    return x + _lin(sd, p + ".mlp.fc2", F.gelu(_lin(sd, p + ".mlp.fc1", h)))
+
+
+def sync_block(sd, p, vis, aud, num_blocks=3):
+    """model/model_utils.py:257-282.  vis [B,C,T,H,W], aud [B,512,F,T']; tables sized to the inputs
+    (the reference sizes them from cfg; F2/F3 in SURVEY.md)."""
+    B = vis.shape[0]
+    v = vis.flatten(2).transpose(1, 2)
+    a = aud.flatten(2).transpose(1, 2)
+    v = _ln(sd, p + ".vis_norm", _lin(sd, p + ".vis_proj", v)) + sinusoid_table(v.shape[1], 512)
+    a = _ln(sd, p + ".aud_norm", a) + sinusoid_table(a.shape[1], 512)
+    x = torch.cat([v, a], 1)
+    for i in range(num_blocks):
+        x = vit_block(sd, "%s.blocks.%d" % (p, i), x, 4)
+    return x
+
+
+def _projector(sd, p, x):
+    x = F.relu(_ln(sd, p + ".1", _lin(sd, p + ".0", x)))
+    x = F.relu(_ln(sd, p + ".4", _lin(sd, p + ".3", x)))
+    return _ln(sd, p + ".7", _lin(sd, p + ".6", x))
+
+
+def _predictor(sd, p, x):
+    return _lin(sd, p + ".3", F.relu(_ln(sd, p + ".1", _lin(sd, p + ".0", x))))
+
+
+def _D(p, z):
+    return -F.cosine_similarity(p, z, dim=-1).mean()  # model/model_utils.py:285-290
+
+
+def readout(sd, p, x):
+    """model/model_utils.py:490-504."""
+    x = _conv3(sd, p + ".0", x)
+    x = F.relu(_bn(sd, p + ".2", _conv3(sd, p + ".1", x, 1, 1), 1e-5))
+    x = F.relu(_bn(sd, p + ".5", _conv3(sd, p + ".4", x, 1, (0, 1, 1)), 1e-5))
+    x = _up(x, 4)
+    x = F.relu(_conv3(sd, p + ".8", x, (4, 1, 1)))
+    x = F.relu(_conv3(sd, p + ".10", x, 1, (0, 1, 1)))
+    return _conv3(sd, p + ".12", x, 1, (0, 1, 1))
+
+
+def decode(sd, feats, masks, lateral_bool, lateral_stride):
+    """Top-down fusion + readout, model/model_utils.py:561-572."""
+    v1, v2, v3, v4 = feats
+    s3 = latlayer(sd, "latlayer_3", v4, lateral_bool[3], lateral_stride[3])
+    s0 = latlayer(sd, "latlayer_0", v1, lateral_bool[0], lateral_stride[0])
+    s1 = latlayer(sd, "latlayer_1", v2, lateral_bool[1], lateral_stride[1])
+    s2 = latlayer(sd, "latlayer_2", v3, lateral_bool[2], lateral_stride[2])
+    s2 = sa_gate(sd, "sa_2", s2, masks, 1) + _up(s3, 2)
+    s1 = sa_gate(sd, "sa_1", s1, masks, 2) + _up(s2, 2) + _up(s3, 4)
+    s0 = sa_gate(sd, "sa_0", s0, masks, 4) + _up(s1, 2) + _up(s2, 4) + _up(s3, 8)
+    out = readout(sd, "readout", torch.cat([s0, _up(s1, 2), _up(s2, 4), _up(s3, 8)], 1))
+    out = out.squeeze(1).squeeze(1)
+    return out - torch.logsumexp(out, dim=(1, 2), keepdim=True)
+
+
+def pack_clips(name, clips):
+    """model/model_utils.py:521-532: SlowFast slow pathway = frames [0,4,12,-1] (F7)."""
+    if name == "slowfast4x16":
+        return [torch.stack([clips[:, :, 0], clips[:, :, 4], clips[:, :, 12], clips[:, :, -1]], 2), clips]
+    if name == "videoswins":
+        return clips
+    return [clips]
+
+
+BACKBONES = {}  # name -> fn(sd, packed_clips, prefix) -> [v1..v4]; filled below and by restate_tx.py
+BACKBONES["x3dl"] = lambda sd, x, prefix: x3d_forward(sd, x[0], prefix)
+
+
+def audio_visual_forward(sd, clips, audios, name, lateral_bool, lateral_stride, num_frames=16):
+    """AudioVisualSaliencyModel.forward, model/model_utils.py:520-574.  Returns (log-prob map, loss)."""
+    B = clips.shape[0]
+    frames = clips.permute(0, 2, 1, 3, 4).reshape(B * clips.shape[2], clips.shape[1], *clips.shape[3:])
+    o1, o0 = static_saliency_encoder(sd, frames)
+    masks = adapter(sd, "adapter", o1, o0, num_frames, num_frames // 4)
+    aud = resnet18_forward(sd, audios, "audnet.")
+    v1, v2, v3, v4 = BACKBONES[name](sd, pack_clips(name, clips), "visnet.")
+    _, _, t, h, w = v4.shape
+    x = sync_block(sd, "aud_vis_sync_block", v4, aud)
+    vis_fea = x[:, : t * h * w].transpose(1, 2).reshape(B, 512, t, h, w)
+    aud_fea = x[:, t * h * w:].transpose(1, 2)
+    vis_emb = _projector(sd, "vis_projector", vis_fea.mean((2, 3, 4)))
+    aud_emb = _projector(sd, "aud_projector", aud_fea.mean(2))
+    loss = (_D(_predictor(sd, "mlp_vis", vis_emb), aud_emb) + _D(_predictor(sd, "mlp_aud", aud_emb), vis_emb)) * 0.5
+    out = decode(sd, (v1, v2, v3, torch.cat([v4, vis_fea], 1)), masks, lateral_bool, lateral_stride)
+    return out, loss
+
+
+def visual_forward(sd, clips, name, lateral_bool, lateral_stride, num_frames=16):
+    """VisualSaliencyModel.forward, model/model_utils.py:685-702.  Returns (log-prob map, 0)."""
+    B = clips.shape[0]
+    frames = clips.permute(0, 2, 1, 3, 4).reshape(B * clips.shape[2], clips.shape[1], *clips.shape[3:])
+    o1, o0 = static_saliency_encoder(sd, frames)
+    masks = adapter(sd, "adapter", o1, o0, num_frames, num_frames // 4)
+    feats = BACKBONES[name](sd, pack_clips(name, clips), "visnet.")
+    return decode(sd, feats, masks, lateral_bool, lateral_stride), 0
