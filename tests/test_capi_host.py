@@ -1,0 +1,163 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mspi_hip.h declares; host-side
+logic (config surface, factory errors, weight packing, algebraic fusions) without any GPU call."""
+import ctypes
+import math
+import os
+import re
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mspi_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mspi_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mspi_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = _lib.load()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert getattr(raw, name) is not None
+    assert lib.mspi_version() == 1
+    assert lib.mspi_last_error() is not None
+
+
+def test_descriptor_validation_without_gpu():
+    """Bad descriptors are rejected on the host before any launch (no GPU needed)."""
+    from mspi_amd import _lib
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    rc = lib.mspi_conv_fwd(ctypes.byref(d), None, None, None, None, None, None, None)
+    assert rc == -1 and b"null" in lib.mspi_last_error()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    d.N = d.T = d.H = d.W = 1
+    d.C = 4
+    d.kT = d.kH = d.kW = d.strT = d.strH = d.strW = 1
+    d.To, d.Ho, d.Wo, d.Cout = 2, 1, 1, 4       # wrong output extent
+    d.ldy = d.ldw = 4
+    assert lib.mspi_conv_fwd(ctypes.byref(d), p, p, None, None, None, p, None) == -1
+    assert b"does not match" in lib.mspi_last_error()
+    a = _lib.AttnDesc()
+    a.B = a.Hh = a.Nq = a.Nk = 1
+    a.D = 48
+    assert lib.mspi_attn_fwd(ctypes.byref(a), p, p, p, p, None) == -1
+    assert b"head_dim" in lib.mspi_last_error()
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from mspi_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.MspiError):
+        _lib.load()
+
+
+def test_ops_refuse_cpu_tensors():
+    from mspi_amd import engine as E
+    from mspi_amd._lib import MspiError
+    pk = E.pack_conv(torch.randn(8, 4, 1, 1, 1))
+    with pytest.raises(MspiError):
+        E.conv(torch.zeros(1, 4, 1, 2, 2), pk)
+
+
+def test_config_surface_matches_reference_fields():
+    from mspi_amd import config as C
+    cfg = C.cfg
+    assert cfg.DATA.NUM_FRAMES == 16 and cfg.DATA.USE_SOUND is True and tuple(cfg.DATA.RESOLUTION) == (224, 384)
+    assert C._MOTION_ENCODERS == ("mvitv2s", "s3d", "slowfast4x16", "morphmlps", "uniformerb", "videoswins", "x3dl")
+    assert cfg.MODEL.MOTION_ENCODER_EMBEDS["x3dl"] == (24, 48, 96, 192)
+    assert cfg.MODEL.NUM_VIS_TOKENS["mvitv2s"] == 8 * 7 * 12 and cfg.MODEL.NUM_VIS_TOKENS["x3dl"] == 16 * 49
+    c = cfg.clone()
+    C.select_model("x3dl", c)
+    assert c.MODEL.LATERAL_STRIDE == [4, 4, 4, 4] and c.MODEL.LATERAL_BOOL == [True] * 4
+    C.select_model("slowfast4x16", c)
+    assert c.MODEL.LATERAL_STRIDE == [2, 2, 2, 2] and c.MODEL.LATERAL_BOOL == [False] * 4
+    assert cfg.MODEL.MOTION_ENCODER != "slowfast4x16" or os.environ.get("MSPI_MOTION_ENCODER") == "slowfast4x16"
+    with pytest.raises(Exception, match="Invalid Motion Encoder!"):
+        C.select_model("resnet3d", c)
+
+
+def test_factory_contract():
+    from mspi_amd import testing as T
+    from mspi_amd.model.get_video_backbones import video_motion_extractor
+    m = video_motion_extractor(T.make_cfg("x3dl"))
+    assert hasattr(m, "load_weight") and len(m.state_dict()) == 1137
+    c = T.make_cfg("x3dl")
+    c.MODEL.MOTION_ENCODER = "bogus"
+    with pytest.raises(Exception, match="Invalid Motion Encoder!"):
+        video_motion_extractor(c)
+
+
+def test_train_mode_is_refused():
+    from mspi_amd.backbones.resnet import ResNet
+    from mspi_amd._lib import MspiError
+    with pytest.raises(MspiError, match="eval"):
+        ResNet().train().forward_cl(torch.zeros(1, 1, 64, 64))
+
+
+def test_pack_conv_folds_bn_and_orders_taps():
+    from mspi_amd import engine as E
+    torch.manual_seed(0)
+    conv = nn.Conv3d(6, 10, (3, 1, 2), bias=True)
+    bn = nn.BatchNorm3d(10, eps=1e-3).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2)
+        bn.weight.normal_()
+        bn.bias.normal_()
+    pk = E.pack_conv(conv.weight, conv.bias, bn, cin_stored=8)
+    assert pk.w.shape == (12, 3 * 1 * 2 * 8) and pk.cout_s == 12 and pk.ldw % 4 == 0
+    x = torch.randn(2, 6, 5, 4, 4)
+    ref = bn(conv(x))
+    # emulate the kernel's A row layout: (tap, ci) with ci fastest, channels padded to 8
+    xp = F.pad(x, (0, 0, 0, 0, 0, 0, 0, 2))
+    cols = torch.stack([xp[:, :, t:t + 3, h, w:w + 2].permute(0, 2, 3, 1).reshape(2, -1)
+                        for t in range(3) for h in range(4) for w in range(3)], 1)   # [N, To*Ho*Wo, K]
+    out = cols @ pk.w.t() + pk.bias
+    got = out[:, :, :10].reshape(2, 3, 4, 3, 10).permute(0, 4, 1, 2, 3)
+    assert (got - ref).abs().max() < 1e-5
+    assert (out[:, :, 10:] == 0).all()
+
+
+def test_lateral_composition_is_exact():
+    from mspi_amd.model.model_utils import _compose_lateral
+    torch.manual_seed(1)
+    c0 = nn.Conv3d(24, 192, 1)
+    c1 = nn.Conv3d(192, 192, (4, 1, 1), stride=(4, 1, 1), bias=False)
+    x = torch.randn(1, 24, 16, 5, 5)
+    w, b = _compose_lateral(c0, c1)
+    with torch.no_grad():
+        assert (F.conv3d(x, w, b, (4, 1, 1)) - c1(c0(x))).abs().max() < 1e-5
+
+
+def test_readout_reorder_is_exact():
+    """upsample x4 then (4,1,1)/4 conv + ReLU == conv then upsample then ReLU (both linear; bias commutes)."""
+    torch.manual_seed(2)
+    c = nn.Conv3d(64, 32, (4, 1, 1), stride=(4, 1, 1))
+    x = torch.randn(1, 64, 4, 7, 7)
+    up = lambda t: F.interpolate(t, scale_factor=(1, 4, 4), mode="trilinear", align_corners=False)
+    with torch.no_grad():
+        assert (F.relu(c(up(x))) - F.relu(up(c(x)))).abs().max() < 1e-5
+
+
+def test_state_dict_roots_match_reference_names():
+    from mspi_amd import testing as T
+    from mspi_amd.model.model_utils import AudioVisualSaliencyModel
+    m = AudioVisualSaliencyModel(T.make_cfg("x3dl"))
+    roots = {k.split(".")[0] for k in m.state_dict()}
+    assert roots == {"audnet", "image_encoder", "visnet", "aud_vis_sync_block", "vis_projector", "mlp_vis",
+                     "aud_projector", "mlp_aud", "latlayer_0", "latlayer_1", "latlayer_2", "latlayer_3", "readout",
+                     "adapter", "sa_0", "sa_1", "sa_2"}
+    sd = m.state_dict()
+    for k in ("visnet.s2.pathway0_res0.branch2.se.fc1.weight", "latlayer_0.2.norm.norm.weight", "readout.12.bias",
+              "sa_0.conv_mask.0.bn.running_var", "adapter.conv.branch1.1.conv_t.weight",
+              "aud_vis_sync_block.blocks.2.attn.qkv.weight", "image_encoder.smooth_1.1.running_mean",
+              "image_encoder.encoder.stages_2.blocks.8.mlp.fc2.bias", "audnet.layer4.0.downsample.0.weight"):
+        assert k in sd, k
+    assert "aud_vis_sync_block.blocks.0.attn.qkv.bias" not in sd and "aud_vis_sync_block.vis_pos_embed" not in sd

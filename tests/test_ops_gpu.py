@@ -1,0 +1,241 @@
+"""Op-level parity of every C-ABI kernel against a plain PyTorch fp32 CPU reference of the same op.
+(Module- and model-level parity against the oracle / golden fixtures: test_parity_gpu.py.)"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(t5, dev, ld=None):
+    """NCDHW cpu tensor -> engine.CL on the GPU (pad channels poisoned with NaN-free junk)."""
+    from mspi_amd import engine as E
+    N, C, T, H, W = t5.shape
+    x = E.alloc(N, T, H, W, C, dev, ld=ld)
+    x.buf.fill_(7.0)
+    x.as_ncdhw().copy_(t5.to(dev))
+    if x.ld > C and x.Cs > C:   # stored pad channels must be finite zeros for the next layer
+        x.buf.view(-1, x.ld)[:, C:x.Cs] = 0
+    return x
+
+
+def _close(got, ref, tol, what=""):
+    err = (got.cpu() - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    assert err <= tol * scale, "%s: max abs err %.3e (scale %.2f)" % (what, err, scale)
+
+
+CONV_CASES = [
+    # (N, Cin, T, H, W, Cout, k, stride, pad, raw_input)
+    (2, 3, 4, 17, 19, 24, (1, 3, 3), (1, 2, 2), (0, 1, 1), True),      # x3d stem conv_xy on NCDHW
+    (2, 3, 4, 16, 16, 96, (1, 4, 4), (1, 4, 4), (0, 0, 0), True),      # convnext stem
+    (1, 1, 1, 33, 29, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3), True),      # audio conv1
+    (2, 24, 3, 9, 11, 54, (1, 1, 1), (1, 1, 1), (0, 0, 0), False),     # x3d a (54 -> padded 56)
+    (2, 54, 3, 9, 11, 24, (1, 1, 1), (1, 1, 1), (0, 0, 0), False),     # x3d c (padded K)
+    (2, 24, 3, 9, 11, 48, (1, 1, 1), (1, 2, 2), (0, 0, 0), False),     # branch1 strided
+    (1, 192, 4, 6, 7, 192, (3, 3, 3), (1, 1, 1), (1, 1, 1), False),    # readout 3x3x3
+    (2, 64, 1, 10, 9, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), False),    # resnet strided 3x3
+    (2, 192, 8, 5, 5, 192, (4, 1, 1), (4, 1, 1), (0, 0, 0), False),    # lateral temporal
+    (1, 208, 4, 5, 5, 208, (3, 1, 1), (1, 1, 1), (1, 0, 0), False),    # sepconv temporal
+    (3, 512, 1, 1, 1, 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0), False),   # tiny-M linear
+    (1, 32, 1, 20, 20, 1, (1, 3, 3), (1, 1, 1), (0, 1, 1), False),     # single output channel
+    (1, 96, 1, 40, 40, 384, (1, 1, 1), (1, 1, 1), (0, 0, 0), False),   # convnext fc1 (128x128 tiles)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_conv(dev, case, act):
+    from mspi_amd import engine as E
+    N, Cin, T, H, W, Cout, k, s, p, raw = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(N, Cin, T, H, W, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) / math.sqrt(Cin * k[0] * k[1] * k[2])
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv3d(x, w, b, s, p)
+    res = torch.randn_like(ref)
+    ref = ref + res
+    ref = {0: ref, 1: F.relu(ref), 2: F.gelu(ref)}[act]
+    pk = E.pack_conv(w, b, None, s, p, act, cin_stored=Cin if raw else E.rup4(Cin), device=dev)
+    xin = x.to(dev) if raw else _cl(x, dev)
+    out = E.conv(xin, pk, res=_cl(res, dev))
+    torch.cuda.synchronize()
+    _close(out.as_ncdhw(Cout), ref, 2e-5, "conv %s" % (case,))
+    if out.Cs > Cout:  # pad columns must hold act(0 + res_pad) = finite
+        assert torch.isfinite(out.buf).all()
+
+
+def test_conv_gate_and_slices(dev):
+    """SE gate + Swish prologue; output into a channel slice of a wider buffer; strided token-slab input."""
+    from mspi_amd import engine as E
+    g = torch.Generator().manual_seed(5)
+    N, C, T, H, W, Co = 2, 54, 2, 5, 6, 24
+    x = torch.randn(N, C, T, H, W, generator=g)
+    gate = torch.rand(N, C, generator=g)
+    w = torch.randn(Co, C, 1, 1, 1, generator=g) / math.sqrt(C)
+    xa = x * gate.view(N, C, 1, 1, 1)
+    ref = F.relu(F.conv3d(xa * torch.sigmoid(xa), w))
+    pk = E.pack_conv(w, None, None, act=E.ACT_RELU, cin_stored=56, device=dev)
+    gpad = torch.zeros(N, 56, device=dev)
+    gpad[:, :C] = gate.to(dev)
+    wide = E.alloc(N, T, H, W, 64, dev)
+    wide.buf.fill_(-3.0)
+    out = E.conv(_cl(x, dev), pk, gate=gpad, out=wide.slice(32, Co))
+    _close(out.as_ncdhw(), ref, 2e-5, "gated conv")
+    assert (wide.as_ncdhw()[:, :32] == -3.0).all() and (wide.as_ncdhw()[:, 56:] == -3.0).all()
+    # token slab: rows [5, 5+T*H*W) of a [N, R, C] sequence buffer
+    R, Cc = 5 + T * H * W + 3, 48
+    seq = torch.randn(N, R, Cc, generator=g)
+    slab = E.CL(seq.to(dev).contiguous().view(-1), 0, N, R, 1, 1, Cc, Cc).tokens(5, T, H, W)
+    w2 = torch.randn(Co, Cc, 2, 1, 1, generator=g) / math.sqrt(2 * Cc)
+    x5 = seq[:, 5:5 + T * H * W].reshape(N, T, H, W, Cc).permute(0, 4, 1, 2, 3)
+    out2 = E.conv(slab, E.pack_conv(w2, None, None, (2, 1, 1), (0, 0, 0), device=dev))
+    _close(out2.as_ncdhw(), F.conv3d(x5, w2, None, (2, 1, 1)), 2e-5, "slab conv")
+
+
+DW_CASES = [
+    (2, 54, 4, 9, 10, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 108, 4, 9, 10, (3, 3, 3), (1, 2, 2), (1, 1, 1)),
+    (1, 24, 6, 7, 7, (5, 1, 1), (1, 1, 1), (2, 0, 0)),
+    (1, 192, 4, 9, 9, (7, 1, 1), (1, 1, 1), (3, 0, 0)),
+    (1, 192, 2, 12, 13, (1, 7, 7), (1, 1, 1), (0, 3, 3)),
+    (3, 96, 1, 14, 14, (1, 7, 7), (1, 1, 1), (0, 3, 3)),
+    (2, 96, 4, 8, 8, (3, 3, 3), (1, 8, 8), (1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("case", DW_CASES)
+def test_dwconv_pool_maxpool(dev, case):
+    from mspi_amd import engine as E
+    N, C, T, H, W, k, s, p = case
+    g = torch.Generator().manual_seed(C + T)
+    x = torch.randn(N, C, T, H, W, generator=g)
+    w = torch.randn(C, 1, *k, generator=g) / math.sqrt(k[0] * k[1] * k[2])
+    b = torch.randn(C, generator=g)
+    ref = F.conv3d(x, w, b, s, p, 1, C)
+    pk = E.pack_dwconv(w, b, None, s, p, E.ACT_SWISH, device=dev)
+    out = E.dwconv(_cl(x, dev), pk)
+    _close(out.as_ncdhw(C), ref * torch.sigmoid(ref), 2e-5, "dwconv swish")
+    pool = torch.zeros(N, E.rup4(C), device=dev)
+    out = E.dwconv(_cl(x, dev), pk, pool=pool, act=E.ACT_NONE)
+    _close(out.as_ncdhw(C), ref, 2e-5, "dwconv")
+    _close(pool[:, :C], ref.sum((2, 3, 4)), 2e-5, "se pool sums")
+    if all(2 * pp <= kk for pp, kk in zip(p, k)):
+        mp = E.maxpool(_cl(x, dev), k, s, p)
+        _close(mp.as_ncdhw(C), F.max_pool3d(x, k, s, p), 0, "maxpool")
+
+
+def test_se_gate(dev):
+    from mspi_amd import engine as E
+    g = torch.Generator().manual_seed(2)
+    N, C, Fh = 3, 56, 8
+    pool = torch.randn(N, C, generator=g) * 50
+    w1, b1 = torch.randn(Fh, C, generator=g) / 7, torch.randn(Fh, generator=g)
+    w2, b2 = torch.randn(C, Fh, generator=g) / 3, torch.randn(C, generator=g)
+    ref = torch.sigmoid(F.linear(F.relu(F.linear(pool / 100.0, w1, b1)), w2, b2))
+    gate = torch.empty(N, C, device=dev)
+    E.se_gate(pool.to(dev), 1 / 100.0, w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), gate)
+    _close(gate, ref, 1e-5, "se gate")
+
+
+@pytest.mark.parametrize("C", [96, 512, 768, 3072])
+def test_layernorm(dev, C):
+    from mspi_amd import engine as E
+    g = torch.Generator().manual_seed(C)
+    N, R = 3, 37
+    x = torch.randn(N, R, C, generator=g) * 3 + 1
+    gm, bt = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    tab = torch.randn(R, C, generator=g)
+    ref = F.layer_norm(x, (C,), gm, bt, 1e-6)
+    xc = E.CL(x.to(dev).view(-1), 0, N, R, 1, 1, C, C)
+    out = E.layernorm(xc, gm.to(dev), bt.to(dev), 1e-6)
+    _close(out.as_rows().view(N, R, C), ref, 2e-5, "layernorm")
+    # into a token slab of a longer sequence, with table add and ReLU
+    seq = E.alloc(N, R + 9, 1, 1, C, dev)
+    seq.buf.fill_(5.0)
+    E.layernorm(xc, gm.to(dev), bt.to(dev), 1e-6, out=seq.tokens(4, R, 1, 1), act=E.ACT_RELU, table=tab.to(dev))
+    got = seq.buf.view(N, R + 9, C)
+    _close(got[:, 4:4 + R], F.relu(ref) + tab, 2e-5, "layernorm slab")
+    assert (got[:, :4] == 5.0).all() and (got[:, 4 + R:] == 5.0).all()
+
+
+@pytest.mark.parametrize("B,H,N,D", [(2, 4, 197, 128), (1, 3, 392, 32), (2, 2, 130, 96), (1, 1, 31, 64), (2, 4, 874, 128)])
+def test_attention(dev, B, H, N, D):
+    from mspi_amd import engine as E
+    g = torch.Generator().manual_seed(N)
+    C = H * D
+    qkv = torch.randn(B, N, 3 * C, generator=g)
+    q, k, v = qkv.view(B, N, 3, H, D).permute(2, 0, 3, 1, 4).double()
+    scale = D ** -0.5
+    ref = ((q @ k.transpose(-2, -1)) * scale).softmax(-1) @ v
+    ref = ref.transpose(1, 2).reshape(B, N, C).float()
+    xc = E.CL(qkv.to(dev).view(-1), 0, B, N, 1, 1, 3 * C, 3 * C)
+    out = E.attention(xc, B, N, H, D, scale)
+    _close(out.as_rows().view(B, N, C), ref, 2e-5, "attention")
+
+
+def test_attention_large_logits(dev):
+    """Forces the online-softmax rescale: one key tile late in the sequence dominates."""
+    from mspi_amd import engine as E
+    B, H, N, D = 1, 1, 160, 32
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(B, N, 3 * D, generator=g)
+    qkv[0, 150, D:2 * D] *= 30.0   # a key with huge norm
+    q, k, v = qkv.view(B, N, 3, H, D).permute(2, 0, 3, 1, 4).double()
+    ref = ((q @ k.transpose(-2, -1)) * D ** -0.5).softmax(-1) @ v
+    xc = E.CL(qkv.to(dev).view(-1), 0, B, N, 1, 1, 3 * D, 3 * D)
+    out = E.attention(xc, B, N, H, D, D ** -0.5)
+    _close(out.as_rows().view(B, N, D), ref.transpose(1, 2).reshape(B, N, D).float(), 2e-5, "attention rescale")
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_upsample_rowgate(dev, k):
+    from mspi_amd import engine as E
+    g = torch.Generator().manual_seed(k)
+    x = torch.randn(2, 24, 3, 5, 7, generator=g)
+    ref = F.interpolate(x, scale_factor=(1, k, k), mode="trilinear", align_corners=False)
+    base = torch.randn_like(ref)
+    dst = _cl(base, dev)
+    E.upsample(_cl(x, dev), k, dst=dst, accumulate=True, act=E.ACT_RELU)
+    _close(dst.as_ncdhw(), F.relu(base + ref), 1e-5, "upsample+add+relu")
+    out = E.upsample(_cl(x, dev), k)
+    _close(out.as_ncdhw(), ref, 1e-5, "upsample")
+    mask = torch.rand(2, 1, 3, 5 * k, 7 * k, generator=g)
+    E.rowgate(out, _cl(mask, dev))
+    _close(out.as_ncdhw(), ref * mask + ref, 1e-5, "rowgate")
+
+
+def test_small_reductions(dev):
+    from mspi_amd import engine as E
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 50176, generator=g) * 4
+    t = x.to(dev).clone()
+    E.logsumexp_sub(t, 3, 50176)
+    _close(t, x - torch.logsumexp(x, 1, keepdim=True), 1e-5, "logsumexp")
+    seq = torch.randn(2, 40, 512, generator=g)
+    sc = E.CL(seq.to(dev).view(-1), 0, 2, 40, 1, 1, 512, 512)
+    out = torch.empty(2, 512, device=dev)
+    E.mean_rows(sc.tokens(7, 5, 2, 3), 2, 30, out)
+    _close(out, seq[:, 7:37].mean(1), 1e-5, "mean_rows")
+    p, z = torch.randn(4, 2048, generator=g), torch.randn(4, 2048, generator=g)
+    loss = torch.zeros(1, device=dev)
+    E.neg_cosine(E.from_rows(p.to(dev)), E.from_rows(z.to(dev)), loss, 0.5, False)
+    E.neg_cosine(E.from_rows(z.to(dev)), E.from_rows(p.to(dev)), loss, 0.5, True)
+    _close(loss, -F.cosine_similarity(p, z, dim=-1).mean().view(1), 1e-5, "neg cosine")
+    a, b = torch.randn(1003, generator=g), torch.randn(1003, generator=g)
+    y = torch.empty(1003, device=dev)
+    E.add(a.to(dev), b.to(dev), y)
+    _close(y, a + b, 0, "add")
+
+
+def test_errors_are_loud(dev):
+    from mspi_amd import engine as E
+    from mspi_amd._lib import MspiError
+    x = E.alloc(1, 1, 4, 4, 8, dev)
+    pk = E.pack_conv(torch.randn(8, 12, 1, 1, 1), device=dev)
+    with pytest.raises(MspiError):
+        E.conv(x, pk)                       # channel mismatch
+    with pytest.raises(MspiError):
+        E.conv(torch.zeros(1, 12, 1, 4, 4), pk)   # CPU tensor: no fallback

@@ -1,0 +1,84 @@
+"""CPU: the oracle restatement (oracle/restate.py) against the golden vectors that
+oracle/gen_golden.py captured from the reference import.  Weights and inputs are rebuilt from
+seeds through the product's own module tree (mspi_amd.testing), so these tests also pin the
+state-dict layout: a changed key/shape/init changes the checksum stored in the fixture."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mspi_amd import testing as T
+from oracle import restate as R
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _err(a, b):
+    return float(np.abs(a.detach().numpy() - b).max())
+
+
+def test_sinusoid_table(golden_dir):
+    g = _g(golden_dir, "sinusoid_90x512")
+    assert _err(R.sinusoid_table(90, 512), g["table"]) == 0.0
+    from mspi_amd.model.model_utils import get_sinusoid_encoding_table
+    assert _err(get_sinusoid_encoding_table(90, 512)[0], g["table"]) == 0.0
+
+
+def test_x3dl_backbone(golden_dir):
+    from mspi_amd.backbones.X3D import X3D
+    from mspi_amd.config import cfg
+    g = _g(golden_dir, "x3dl_backbone_64")
+    m = T.seeded(lambda: X3D(cfg.MODEL.X3D.PATH_CFG), int(g["seed"]))
+    sd = m.state_dict()
+    assert len(sd) == 1137 and T.sd_checksum(sd) == int(g["sd_crc"])
+    clips, _ = T.synth_inputs(int(g["batch"]), 16, int(g["size"]), int(g["size"]), seed=int(g["seed"]))
+    with torch.no_grad():
+        feats = R.x3d_forward(sd, clips)
+    for i, f in enumerate(feats):
+        assert _err(f, g["v%d" % (i + 1)]) <= 1e-5
+
+
+@pytest.mark.parametrize("wa", [111, 300])
+def test_resnet18_audio(golden_dir, wa):
+    from mspi_amd.backbones.resnet import ResNet
+    g = _g(golden_dir, "resnet18_audio_%d" % wa)
+    m = T.seeded(ResNet, int(g["seed"]))
+    sd = m.state_dict()
+    assert T.sd_checksum(sd) == int(g["sd_crc"])
+    _, audio = T.synth_inputs(int(g["batch"]), Wa=wa, H=8, W=8, seed=int(g["seed"]))
+    with torch.no_grad():
+        out = R.resnet18_forward(sd, audio)
+    assert tuple(out.shape) == (2, 512, 9, (wa + 31) // 32)
+    assert _err(out, g["out"]) <= 1e-5 * max(1.0, float(np.abs(g["out"]).max()))
+
+
+def _model(g, name, cls):
+    from mspi_amd.model import model_utils as pm
+    cfg = T.make_cfg(name, num_aud_tokens=int(g["num_aud_tokens"]), num_vis_tokens=int(g["num_vis_tokens"]))
+    m = T.seeded(lambda: getattr(pm, cls)(cfg), int(g["seed"]))
+    sd = m.state_dict()
+    assert T.sd_checksum(sd) == int(g["sd_crc"]), "seeded weights drifted from the ones the golden was made with"
+    clips, audio = T.synth_inputs(int(g["batch"]), 16, int(g["size"]), int(g["size"]), Wa=int(g["wa"]), seed=int(g["seed"]))
+    return cfg, sd, clips, audio
+
+
+@pytest.mark.parametrize("case", ["av_x3dl_64", "av_x3dl_224"])
+def test_audio_visual_model(golden_dir, case):
+    g = _g(golden_dir, case)
+    cfg, sd, clips, audio = _model(g, "x3dl", "AudioVisualSaliencyModel")
+    with torch.no_grad():
+        out, loss = R.audio_visual_forward(sd, clips, audio, "x3dl", cfg.MODEL.LATERAL_BOOL, cfg.MODEL.LATERAL_STRIDE)
+    assert tuple(out.shape) == g["out"].shape
+    assert _err(out, g["out"]) <= 5e-5 and abs(float(loss) - float(g["loss"])) <= 1e-5
+    assert abs(float(torch.logsumexp(out[0], (0, 1)))) < 1e-4   # F1: a log-probability map
+
+
+def test_visual_model(golden_dir):
+    g = _g(golden_dir, "vis_x3dl_64")
+    cfg, sd, clips, _ = _model(g, "x3dl", "VisualSaliencyModel")
+    with torch.no_grad():
+        out, zero = R.visual_forward(sd, clips, "x3dl", cfg.MODEL.LATERAL_BOOL, cfg.MODEL.LATERAL_STRIDE)
+    assert zero == 0 and _err(out, g["out"]) <= 5e-5
