@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- MSPI saliency-inference hot path on MI355X.
+
+One "step" = one forward of AudioVisualSaliencyModel (X3D-L motion encoder + ConvNeXt-T image
+encoder + VGGSound ResNet-18 + SyncBlock + decoder) over one batch of synthetic clips that is
+already resident in HBM: BASELINE.json configs[1] = batch 8 per GPU of 16x224x224 RGB clips +
+1x257x300 log-spectrograms, fp32, random weights of the real architecture.  Weak scaling: every
+rank runs its own batch of 8; rank 0 broadcasts the weights once (RCCL) and gathers the maps every
+step.  Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU (BASELINE configs[1]: 8)")
+    ap.add_argument("--model", default="x3dl")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--wa", type=int, default=300, help="spectrogram columns (BASELINE: 300; reference default 111)")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel timing table to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, cfg, name, clips, audio, budget_s=25.0):
+    """The oracle (CPU restatement pinned to the reference) on the host cores of this box: B=1 clips,
+    repeated until ~budget_s of CPU work.  A reported baseline, not the target."""
+    from oracle import restate as R
+    n = 0
+    t0 = time.time()
+    with torch.no_grad():
+        while True:
+            R.audio_visual_forward(sd, clips[n % clips.shape[0]:n % clips.shape[0] + 1],
+                                   audio[n % audio.shape[0]:n % audio.shape[0] + 1], name,
+                                   cfg.MODEL.LATERAL_BOOL, cfg.MODEL.LATERAL_STRIDE)
+            n += 1
+            el = time.time() - t0
+            if el > budget_s or (n >= 3 and el > 0.6 * budget_s):
+                break
+    return {"value": round(n / el, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d single-clip forwards of the same workload (B=1) through oracle/restate.py, torch %s CPU fp32"
+                      % (n, torch.__version__)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mspi_amd import engine as E
+    from mspi_amd import testing as T
+    from mspi_amd.model.model_utils import AudioVisualSaliencyModel
+
+    name, B, S = args.model, args.batch, args.size
+    t_tok = {"x3dl": 16, "slowfast4x16": 4}.get(name, 8)
+    cfg = T.make_cfg(name, num_aud_tokens=9 * ((args.wa + 31) // 32), num_vis_tokens=t_tok * (S // 32) ** 2)
+    devnull = open(os.devnull, "w")
+    so, sys.stdout = sys.stdout, devnull          # the constructors print; keep stdout to the one JSON line
+    try:
+        model = T.seeded(lambda: AudioVisualSaliencyModel(cfg), 0)
+    finally:
+        sys.stdout = so
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    model = model.to(dev)
+    if world > 1:   # weight fan-out: one flat RCCL broadcast from rank 0 (xGMI), then unflatten in place
+        tensors = [t for t in list(model.parameters()) + list(model.buffers()) if t.is_floating_point()]
+        flat = torch.cat([t.detach().reshape(-1) for t in tensors])
+        dist.broadcast(flat, 0)
+        off = 0
+        with torch.no_grad():
+            for t in tensors:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+        model._invalidate()
+    clips, audio = T.synth_inputs(B, 16, S, S, Wa=args.wa, seed=100 + rank, device=dev)
+
+    gathered = [torch.empty(B, S, S, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    out, loss = model(clips, audio)               # packs weights, warms the allocator
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model(clips, audio)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out, loss = model(clips, audio)
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            o = out
+        else:
+            o, _ = model(clips, audio)
+        if world > 1:                             # map collection over xGMI
+            dist.gather(o, gathered, dst=0)
+        return o
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    ok = bool(torch.isfinite(out).all().item()) and abs(torch.logsumexp(out.flatten(1), 1)).max().item() < 1e-3
+    if not ok:
+        raise SystemExit("bench: the saliency maps are not finite log-probability maps")
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    line = {
+        "metric": "clips_per_sec", "value": round(world * B * args.steps / elapsed, 3), "unit": "clips/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "ms_per_clip": round(1e3 * elapsed / args.steps / B, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s motion encoder + ConvNeXt-T + ResNet18 audio + SyncBlock + decoder (AudioVisualSaliencyModel "
+                               "forward), batch %d/GPU, clips 3x16x%dx%d, spectrogram 1x257x%d, inputs resident in HBM"
+                               % (name, B, S, S, args.wa),
+                   "global_batch": world * B, "launch": "eager" if graph is None else "hipGraph replay",
+                   "parallelism": "clip-sharded x%d (weights broadcast once, maps gathered per step over RCCL)" % world
+                   if world > 1 else "single GPU"},
+    }
+
+    if not args.no_roofline:
+        # per-launch HIP-event timing of every C-ABI call, eager, same inputs, same stream
+        with E.Profiler() as prof:
+            for _ in range(3):
+                model(clips, audio)
+        torch.cuda.synchronize()
+        summ = prof.summary()
+        tot = sum(d["ms"] for d in summ.values())
+        if args.kernel_table:
+            for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+                sys.stderr.write("%-28s calls %5d  %8.3f ms/step (%4.1f%%)  %7.2f TFLOP/s  %7.1f GB/s (algorithmic)\n" % (
+                    k, d["calls"] // 3, d["ms"] / 3, 100 * d["ms"] / tot, d["flops"] / d["ms"] / 1e9, d["bytes"] / d["ms"] / 1e6))
+        kname, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        tflops = d["flops"] / d["ms"] / 1e9
+        gbs = d["bytes"] / d["ms"] / 1e6
+        mfma_bound = kname.startswith("conv_gemm") or kname == "attention"
+        if mfma_bound and tflops / FP32_MFMA_PEAK_TFLOPS >= gbs / HBM_PEAK_GBS:
+            line["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(tflops, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None}
+        else:
+            line["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
+        line["roofline"]["launches_per_step"] = d["calls"] // 3
+        line["roofline"]["avg_launch_us"] = round(1e3 * d["ms"] / d["calls"], 3)
+        line["roofline"]["share_of_step"] = round(d["ms"] / tot, 4)
+
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, name, clips.cpu(), audio.cpu())
+
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

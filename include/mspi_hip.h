@@ -79,6 +79,10 @@ int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float* w, const f
                   const float* res /*NULL or [M][ldr]*/, const float* gate /*NULL or [N][C]*/,
                   float* y, mspi_stream_t stream);
 
+/* Which kernel instantiation the calling thread's last mspi_conv_fwd launched:
+ * (BM << 16) | (BN << 4) | loader (0 = 16-B vector gather, 1 = scalar gather).  For profiling. */
+int mspi_conv_last_config(void);
+
 /* ------------------------------------------------------------------------------------
  * Depthwise convolution, channels-last, bias (= folded BN) + activation fused; optional
  * per-(n,c) sums of the pre-activation output for squeeze-excite (atomics into `pool`,

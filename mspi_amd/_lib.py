@@ -59,6 +59,7 @@ _SIGNATURES = {
     "mspi_version": (C.c_int, []),
     "mspi_last_error": (C.c_char_p, []),
     "mspi_device_count": (C.c_int, []),
+    "mspi_conv_last_config": (C.c_int, []),
     "mspi_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "mspi_dwconv_fwd": (C.c_int, [C.POINTER(DwConvDesc), _P, _P, _P, _P, _P, _P]),
     "mspi_se_gate": (C.c_int, [_P, C.c_float, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),

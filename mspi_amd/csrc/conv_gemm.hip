@@ -261,6 +261,9 @@ static void launch_cfg(const ConvArgs& a, bool v4, hipStream_t s) {
 
 using namespace mspi;
 
+static thread_local int g_last_cfg = 0;
+extern "C" int mspi_conv_last_config(void) { return g_last_cfg; }
+
 extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float* w, const float* bias,
                              const float* res, const float* gate, float* y, mspi_stream_t stream) {
   MSPI_REQUIRE(d && x && w && y, "mspi_conv_fwd: null argument");
@@ -318,6 +321,7 @@ extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float*
   MSPI_REQUIRE(nb < (1L << 31), "mspi_conv_fwd: grid too large");
   a.nblocks = (int)nb;
   hipStream_t s = (hipStream_t)stream;
+  g_last_cfg = (BMs << 16) | (BNs << 4) | (v4 ? 0 : 1);
   switch (best) {
     case 0: launch_cfg<128, 128, 2, 2>(a, v4, s); break;
     case 1: launch_cfg<128, 64, 2, 2>(a, v4, s); break;

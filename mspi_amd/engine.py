@@ -26,6 +26,54 @@ def rup4(c):
     return (c + 3) // 4 * 4
 
 
+# ----------------------------------------------------------------------------- per-launch timing
+class Profiler:
+    """Per-launch HIP-event timing of the C-ABI calls, on the stream the kernels are launched on
+    (torch's current stream).  Used by bench.py for the roofline line; off by default."""
+    active = None
+
+    def __init__(self):
+        self.records = []   # (kernel_name, flops, bytes, start_event, end_event)
+
+    def __enter__(self):
+        Profiler.active = self
+        return self
+
+    def __exit__(self, *a):
+        Profiler.active = None
+
+    def summary(self):
+        """{kernel: dict(calls, ms, flops, bytes)} -- call after torch.cuda.synchronize()."""
+        out = {}
+        for name, fl, by, e0, e1 in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += by
+        return out
+
+
+class _Timed:
+    __slots__ = ("name", "flops", "bytes", "e0")
+
+    def __init__(self, name, flops=0.0, nbytes=0.0):
+        self.name, self.flops, self.bytes = name, flops, nbytes
+
+    def __enter__(self):
+        if Profiler.active is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        p = Profiler.active
+        if p is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            p.records.append((self.name, self.flops, self.bytes, self.e0, e1))
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -225,9 +273,17 @@ def conv(x, pk, out=None, res=None, gate=None, act=None):
     d.act = pk.act if act is None else act
     if res is not None and (res.M != out.M or not res.dense):
         raise MspiError("conv: residual rows %d != output rows %d (or residual not dense)" % (res.M, out.M))
-    check(lib.mspi_conv_fwd(C.byref(d), xptr, pk.w.data_ptr(), pk.bias.data_ptr() if pk.bias is not None else None,
-                            res.ptr if res is not None else None, gate.data_ptr() if gate is not None else None,
-                            out.ptr, _stream()), "mspi_conv_fwd")
+    M = N * To * Ho * Wo
+    taps = pk.k[0] * pk.k[1] * pk.k[2]
+    tm = _Timed("conv_gemm", 2.0 * M * taps * pk.cin * pk.cout,
+                4.0 * (N * T * H * W * pk.cin + M * pk.cout * (2 if res is not None else 1) + pk.cout * taps * pk.cin))
+    with tm:
+        check(lib.mspi_conv_fwd(C.byref(d), xptr, pk.w.data_ptr(), pk.bias.data_ptr() if pk.bias is not None else None,
+                                res.ptr if res is not None else None, gate.data_ptr() if gate is not None else None,
+                                out.ptr, _stream()), "mspi_conv_fwd")
+        if Profiler.active is not None:
+            c = lib.mspi_conv_last_config()
+            tm.name = "conv_gemm<%d,%d,%s>" % (c >> 16, (c >> 4) & 0xFFF, "s" if c & 1 else "v4")
     return out
 
 
@@ -253,8 +309,10 @@ def dwconv(x, pk, out=None, pool=None, act=None):
         out = alloc(x.N, To, Ho, Wo, x.C, x.buf.device)
     d = _dw_desc(x, pk.k, pk.stride, pk.pad, out.ld)
     d.act = pk.act if act is None else act
-    check(lib.mspi_dwconv_fwd(C.byref(d), x.ptr, pk.w.data_ptr(), pk.bias.data_ptr(), out.ptr,
-                              pool.data_ptr() if pool is not None else None, _stream()), "mspi_dwconv_fwd")
+    taps = pk.k[0] * pk.k[1] * pk.k[2]
+    with _Timed("dwconv_pool" if pool is not None else "dwconv", 2.0 * out.M * taps * pk.c, 4.0 * (x.M + out.M) * pk.c):
+        check(lib.mspi_dwconv_fwd(C.byref(d), x.ptr, pk.w.data_ptr(), pk.bias.data_ptr(), out.ptr,
+                                  pool.data_ptr() if pool is not None else None, _stream()), "mspi_dwconv_fwd")
     return out
 
 
@@ -266,7 +324,8 @@ def maxpool(x, k, s, p, out=None):
         out = alloc(x.N, To, Ho, Wo, x.C, x.buf.device)
     d = _dw_desc(x, k, s, p, out.ld)
     d.act = ACT_NONE
-    check(lib.mspi_maxpool_fwd(C.byref(d), x.ptr, out.ptr, _stream()), "mspi_maxpool_fwd")
+    with _Timed("maxpool", 0.0, 4.0 * (x.M + x.N * To * Ho * Wo) * x.C):
+        check(lib.mspi_maxpool_fwd(C.byref(d), x.ptr, out.ptr, _stream()), "mspi_maxpool_fwd")
     return out
 
 
@@ -288,9 +347,10 @@ def layernorm(x, gamma, beta, eps, out=None, act=ACT_NONE, table=None):
     assert out.N == x.N and out.T * out.H * out.W == R and out.C == x.C
     P = 0 if table is None else table.shape[0]
     assert table is None or P == R
-    check(lib.mspi_layernorm_fwd(x.ptr, x.ld, x.sN, out.ptr, out.ld, out.sN, gamma.data_ptr(), beta.data_ptr(),
-                                 float(eps), x.N, R, x.C, act, table.data_ptr() if table is not None else None,
-                                 _stream()), "mspi_layernorm_fwd")
+    with _Timed("layernorm", 8.0 * x.M * x.C, 8.0 * x.M * x.C):
+        check(lib.mspi_layernorm_fwd(x.ptr, x.ld, x.sN, out.ptr, out.ld, out.sN, gamma.data_ptr(), beta.data_ptr(),
+                                     float(eps), x.N, R, x.C, act, table.data_ptr() if table is not None else None,
+                                     _stream()), "mspi_layernorm_fwd")
     return out
 
 
@@ -310,7 +370,8 @@ def attention(qkv, B, Ntok, heads, hd, scale, out=None):
     d.o_sB, d.o_sH, d.o_sT = Ntok * out.ld, hd, out.ld
     d.scale = float(scale)
     base = qkv.ptr
-    check(lib.mspi_attn_fwd(C.byref(d), base, base + 4 * Cc, base + 8 * Cc, out.ptr, _stream()), "mspi_attn_fwd")
+    with _Timed("attention", 4.0 * B * heads * Ntok * Ntok * hd, 16.0 * B * Ntok * Cc):
+        check(lib.mspi_attn_fwd(C.byref(d), base, base + 4 * Cc, base + 8 * Cc, out.ptr, _stream()), "mspi_attn_fwd")
     return out
 
 
@@ -322,8 +383,9 @@ def upsample(src, factor, dst=None, accumulate=False, act=ACT_NONE):
         dst = alloc(src.N, src.T, src.H * factor, src.W * factor, src.C, src.buf.device)
     assert (dst.N, dst.T, dst.H, dst.W) == (src.N, src.T, src.H * factor, src.W * factor) and dst.C == src.C
     assert dst.dense
-    check(lib.mspi_upsample_fwd(src.ptr, src.ld, dst.ptr, dst.ld, src.N * src.T, src.H, src.W, src.Cs, factor,
-                                1 if accumulate else 0, act, _stream()), "mspi_upsample_fwd")
+    with _Timed("upsample", 0.0, 4.0 * (src.M + dst.M * (2 if accumulate else 1)) * src.C):
+        check(lib.mspi_upsample_fwd(src.ptr, src.ld, dst.ptr, dst.ld, src.N * src.T, src.H, src.W, src.Cs, factor,
+                                    1 if accumulate else 0, act, _stream()), "mspi_upsample_fwd")
     return dst
 
 
@@ -331,7 +393,8 @@ def rowgate(x, mask):
     lib = _lib.load()
     assert mask.M == x.M and mask.ld == 1
     assert x.dense and mask.dense
-    check(lib.mspi_rowgate(x.ptr, x.ld, mask.ptr, x.M, x.Cs, _stream()), "mspi_rowgate")
+    with _Timed("rowgate", 0.0, 8.0 * x.M * x.C):
+        check(lib.mspi_rowgate(x.ptr, x.ld, mask.ptr, x.M, x.Cs, _stream()), "mspi_rowgate")
     return x
 
 
