@@ -56,8 +56,8 @@ class ResNetBasicStem(HipModule):
         c = self.conv
         return E.pack_conv(c.weight, None, self.bn, c.stride, c.padding, E.ACT_RELU)
 
-    def run(self, x):
-        return E.maxpool(E.conv(x, self.pk), (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    def run(self, x, out=None):
+        return E.maxpool(E.conv(x, self.pk), (1, 3, 3), (1, 2, 2), (0, 1, 1), out=out)
 
 
 class VideoModelStem(HipModule):
@@ -70,9 +70,11 @@ class VideoModelStem(HipModule):
             self.add_module("pathway{}_stem".format(p),
                             stem(dim_in[p], dim_out[p], kernel[p], stride[p], padding[p], eps, bn_mmt))
 
-    def run(self, xs):
+    def run(self, xs, outs=None):
         assert len(xs) == self.num_pathways
-        return [getattr(self, "pathway{}_stem".format(p)).run(xs[p]) for p in range(self.num_pathways)]
+        if outs is None:
+            return [getattr(self, "pathway{}_stem".format(p)).run(xs[p]) for p in range(self.num_pathways)]
+        return [getattr(self, "pathway{}_stem".format(p)).run(xs[p], out=outs[p]) for p in range(self.num_pathways)]
 
 
 def _se_width(width, ratio, min_width=8, divisor=8):
@@ -142,7 +144,7 @@ class X3DTransform(HipModule):
                         E._pad_vec(self.se.fc2.bias, cs_mid))
         return pk
 
-    def run(self, x, res, scratch):
+    def run(self, x, res, scratch, out=None):
         """res: skip tensor added before the final ReLU; scratch: zeroed [N, C_mid_stored] pool slab or None."""
         pk = self.pk
         t = E.conv(x, pk["a"])
@@ -150,9 +152,9 @@ class X3DTransform(HipModule):
             u = E.dwconv(t, pk["b"], pool=scratch)
             gate = torch.empty_like(scratch)
             E.se_gate(scratch, 1.0 / (u.T * u.H * u.W), *pk["se"], gate)
-            return E.conv(u, pk["c"], res=res, gate=gate)
+            return E.conv(u, pk["c"], res=res, gate=gate, out=out)
         u = E.dwconv(t, pk["b"])
-        return E.conv(u, pk["c"], res=res)
+        return E.conv(u, pk["c"], res=res, out=out)
 
 
 class BottleneckTransform(HipModule):
@@ -175,9 +177,9 @@ class BottleneckTransform(HipModule):
         return {n: E.pack_conv(c.weight, None, bn, c.stride, c.padding, E.ACT_RELU, cin_stored=E.rup4(c.in_channels))
                 for n, c, bn in (("a", self.a, self.a_bn), ("b", self.b, self.b_bn), ("c", self.c, self.c_bn))}
 
-    def run(self, x, res, scratch=None):
+    def run(self, x, res, scratch=None, out=None):
         pk = self.pk
-        return E.conv(E.conv(E.conv(x, pk["a"]), pk["b"]), pk["c"], res=res)
+        return E.conv(E.conv(E.conv(x, pk["a"]), pk["b"]), pk["c"], res=res, out=out)
 
 
 class ResBlock(HipModule):
@@ -205,9 +207,9 @@ class ResBlock(HipModule):
         b2 = self.branch2
         return E.rup4(b2.a.out_channels) if hasattr(b2, "se") else 0
 
-    def run(self, x, scratch=None):
+    def run(self, x, scratch=None, out=None):
         skip = E.conv(x, self.pk) if self.pk is not None else x
-        return self.branch2.run(x, skip, scratch)
+        return self.branch2.run(x, skip, scratch, out=out)
 
 
 class ResStage(HipModule):
@@ -234,18 +236,23 @@ class ResStage(HipModule):
     def se_floats(self, p=0):
         return sum(b.se_width() for b in self.blocks(p))
 
-    def run(self, xs, scratch=None):
-        """scratch: zeroed flat tensor with N*se_floats() floats (X3D only)."""
+    def run(self, xs, scratch=None, outs=None, pathways=None):
+        """scratch: zeroed flat tensor with N*se_floats() floats (X3D only).  outs[p]: where pathway p's
+        last block writes (a channel slice of a concat buffer).  pathways: subset to compute."""
         out = []
         for p in range(self.num_pathways):
+            if pathways is not None and p not in pathways:
+                out.append(None)
+                continue
             x = xs[p]
             off = 0
-            for b in self.blocks(p):
+            blocks = self.blocks(p)
+            for bi, b in enumerate(blocks):
                 w = b.se_width()
                 slab = None
                 if w:
                     slab = scratch[off: off + x.N * w].view(x.N, w)
                     off += x.N * w
-                x = b.run(x, slab)
+                x = b.run(x, slab, out=outs[p] if (outs is not None and bi == len(blocks) - 1) else None)
             out.append(x)
         return out

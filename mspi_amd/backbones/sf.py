@@ -1,0 +1,125 @@
+"""SlowFast (4x16, R50) backbone, features only, HIP-backed.  Mirrors backbones/sf.py:101-388 of the
+reference: same constructor argument, sub-module names (s1, s1_fuse, s2, ..., s5, pathway{0,1}_pool)
+and outputs: the slow pathway after each lateral fusion (320/640/1280 ch) and after s5 (2048 ch).
+
+Every torch.cat([slow, fuse]) (backbones/sf.py:158) is gone: the slow pathway's last block and the
+fusion conv write into the two channel slices of one buffer.  The fast pathway of s5 is computed and
+thrown away upstream (backbones/sf.py:380-382); it is simply not launched here."""
+import torch
+import torch.nn as nn
+
+from .. import engine as E
+from ..backbone_cfg import load_backbone_cfg
+from ..module import HipModule
+from . import blocks3d as B
+
+_MODEL_STAGE_DEPTH = {18: (2, 2, 2, 2), 50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+_SF_TEMPORAL_KERNELS = [[[1], [5]], [[1], [3]], [[1], [3]], [[3], [3]], [[3], [3]]]  # conv1, res2..res5 (slow, fast)
+
+
+class FuseFastToSlow(HipModule):
+    """Strided temporal conv (k,1,1)/(alpha,1,1) + BN + ReLU on the fast pathway, concatenated to the slow one."""
+
+    def __init__(self, dim_in, fusion_conv_channel_ratio, fusion_kernel, alpha, eps=1e-5, bn_mmt=0.1):
+        super().__init__()
+        self.conv_f2s = nn.Conv3d(dim_in, dim_in * fusion_conv_channel_ratio, kernel_size=[fusion_kernel, 1, 1],
+                                  stride=[alpha, 1, 1], padding=[fusion_kernel // 2, 0, 0], bias=False)
+        self.bn = nn.BatchNorm3d(dim_in * fusion_conv_channel_ratio, eps=eps, momentum=bn_mmt)
+        self.relu = nn.ReLU(True)
+
+    @property
+    def out_channels(self):
+        return self.conv_f2s.out_channels
+
+    def _pack(self):
+        c = self.conv_f2s
+        return E.pack_conv(c.weight, None, self.bn, c.stride, c.padding, E.ACT_RELU)
+
+    def run(self, x_fast, out):
+        return E.conv(x_fast, self.pk, out=out)
+
+
+class SlowFast(HipModule):
+    def __init__(self, path_to_config):
+        super().__init__()
+        cfg = None
+        for p in path_to_config:
+            cfg = load_backbone_cfg(p)
+        assert cfg.MODEL.ARCH == "slowfast" and cfg.RESNET.DEPTH in _MODEL_STAGE_DEPTH
+        self.cfg = cfg
+        self.num_pathways = 2
+        depths = _MODEL_STAGE_DEPTH[cfg.RESNET.DEPTH]
+        sf, rn = cfg.SLOWFAST, cfg.RESNET
+        wpg = rn.WIDTH_PER_GROUP
+        dim_inner = rn.NUM_GROUPS * wpg
+        odr = sf.BETA_INV // sf.FUSION_CONV_CHANNEL_RATIO
+        tk = _SF_TEMPORAL_KERNELS
+        self.s1 = B.VideoModelStem(dim_in=cfg.DATA.INPUT_CHANNEL_NUM, dim_out=[wpg, wpg // sf.BETA_INV],
+                                   kernel=[tk[0][0] + [7, 7], tk[0][1] + [7, 7]], stride=[[1, 2, 2]] * 2,
+                                   padding=[[tk[0][0][0] // 2, 3, 3], [tk[0][1][0] // 2, 3, 3]])
+        self.s1_fuse = FuseFastToSlow(wpg // sf.BETA_INV, sf.FUSION_CONV_CHANNEL_RATIO, sf.FUSION_KERNEL_SZ, sf.ALPHA)
+        widths = [wpg, wpg * 4, wpg * 8, wpg * 16, wpg * 32]       # slow pathway width after s1..s5
+        for i in range(4):
+            w_in, w_out = widths[i], widths[i + 1]
+            stage = B.ResStage(dim_in=[w_in + w_in // odr, w_in // sf.BETA_INV],
+                               dim_out=[w_out, w_out // sf.BETA_INV],
+                               dim_inner=[dim_inner * 2 ** i, dim_inner * 2 ** i // sf.BETA_INV],
+                               temp_kernel_sizes=tk[i + 1], stride=rn.SPATIAL_STRIDES[i], num_blocks=[depths[i]] * 2,
+                               num_groups=[rn.NUM_GROUPS] * 2, num_block_temp_kernel=rn.NUM_BLOCK_TEMP_KERNEL[i],
+                               nonlocal_inds=cfg.NONLOCAL.LOCATION[i], trans_func_name=rn.TRANS_FUNC,
+                               stride_1x1=rn.STRIDE_1X1, dilation=rn.SPATIAL_DILATIONS[i])
+            self.add_module("s%d" % (i + 2), stage)
+            if i < 3:
+                self.add_module("s%d_fuse" % (i + 2), FuseFastToSlow(w_out // sf.BETA_INV, sf.FUSION_CONV_CHANNEL_RATIO,
+                                                                     sf.FUSION_KERNEL_SZ, sf.ALPHA))
+            if i == 0:
+                for p in range(2):   # pool1 of the "slowfast" arch is [1,1,1]: the identity (backbones/sf.py _POOL1)
+                    self.add_module("pathway{}_pool".format(p), nn.MaxPool3d(kernel_size=[1, 1, 1], stride=[1, 1, 1],
+                                                                             padding=[0, 0, 0]))
+
+    @staticmethod
+    def _fused_buffer(x_slow_shape, c_slow, c_fuse, dev):
+        N, T, H, W = x_slow_shape
+        buf = E.alloc(N, T, H, W, c_slow + c_fuse, dev)
+        return buf, buf.slice(0, c_slow), buf.slice(c_slow, c_fuse)
+
+    @torch.no_grad()
+    def forward_cl(self, x):
+        """x: [clips_slow [N,3,T/alpha,H,W], clips_fast [N,3,T,H,W]] -> 4 CL features of the slow pathway."""
+        self._check_eval()
+        slow_in, fast_in = x
+        dev = fast_in.device
+        N, _, Ts, H, W = slow_in.shape
+        c0 = self.s1.pathway0_stem.conv.out_channels
+        buf, sl, fu = self._fused_buffer((N, Ts, H // 4, W // 4), c0, self.s1_fuse.out_channels, dev)
+        _, fast = self.s1.run([slow_in, fast_in], outs=[sl, None])
+        self.s1_fuse.run(fast, fu)
+        xs = [buf, fast]
+        feats = []
+        for i in range(4):
+            stage = getattr(self, "s%d" % (i + 2))
+            if i < 3:
+                fuse = getattr(self, "s%d_fuse" % (i + 2))
+                st = stage.blocks(0)[0].branch2.b.stride[1]
+                blk = stage.blocks(0)[-1]
+                c_slow = blk.branch2.c.out_channels
+                buf, sl, fu = self._fused_buffer((N, xs[0].T, xs[0].H // st, xs[0].W // st), c_slow, fuse.out_channels, dev)
+                _, fast = stage.run(xs, outs=[sl, None])
+                fuse.run(fast, fu)
+                xs = [buf, fast]
+                feats.append(buf)
+            else:
+                feats.append(stage.run(xs, pathways=(0,))[0])   # F8: the fast half of s5 is dead code upstream
+        return feats
+
+    def forward(self, x, bboxes=None):
+        return [f.as_ncdhw() for f in self.forward_cl(x)]
+
+    def load_weight(self, path):
+        """The released SLOWFAST_4x16_R50.pkl is a caffe2 pickle that upstream converts by name
+        (SlowFast/slowfast/utils/checkpoint.py:191-...); that converter is a 'next' row.
+        PyTorch-format checkpoints ({'model_state': ...} or a bare state dict) load directly."""
+        if str(path).endswith(".pkl"):
+            raise NotImplementedError("caffe2 .pkl conversion is not part of the hot path (SURVEY.md section 8f, rank 1)")
+        ck = torch.load(path, map_location="cpu")
+        self.load_state_dict(ck.get("model_state", ck), strict=False)

@@ -91,3 +91,16 @@ def synth_inputs(B, T=16, H=224, W=224, Wa=111, seed=0, device="cpu"):
     clips = approx_normal(B, 3, T, H, W)
     audio = approx_normal(B, 1, 257, Wa)
     return clips.to(device), audio.to(device)
+
+
+def feature_error(feat, g, key):
+    """Relative max error of a feature map against a strided-sample golden (oracle/gen_golden.py::_feat_fixture);
+    also checks shape and whole-tensor mean."""
+    f = feat.detach().float().cpu()
+    assert tuple(f.shape) == tuple(int(v) for v in g[key + "_shape"]), (tuple(f.shape), g[key + "_shape"])
+    flat = f.reshape(-1)
+    ref = torch.as_tensor(g[key + "_sample"])
+    scale = float(g[key + "_absmax"])
+    err = (flat[::int(g[key + "_stride"])] - ref).abs().max().item() / max(scale, 1e-6)
+    merr = abs(flat.double().mean().item() - float(g[key + "_mean"])) / max(scale, 1e-6)
+    return max(err, merr)

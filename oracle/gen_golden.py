@@ -60,13 +60,15 @@ def build_reference_model(name, cls_name, num_vis_tokens=None):
         cfg.MODEL.NUM_VIS_TOKENS[name] = num_vis_tokens
     rh.set_create_model(lambda *a, **k: _RefConvNeXt())
     import model.model_utils as mu
-    real_load, real_lsd = torch.load, nn.Module.load_state_dict
+    import backbones.sf as ref_sf
+    real_load, real_lsd, real_sf_lw = torch.load, nn.Module.load_state_dict, ref_sf.SlowFast.load_weight
+    ref_sf.SlowFast.load_weight = lambda self, path: None    # caffe2 .pkl loader opens the (absent) file itself
     torch.load = lambda *a, **k: _NoWeights()
     nn.Module.load_state_dict = lambda self, sd, *a, **k: None if isinstance(sd, _NoWeights) else real_lsd(self, sd, *a, **k)
     try:
         m = getattr(mu, cls_name)(cfg)
     finally:
-        torch.load, nn.Module.load_state_dict = real_load, real_lsd
+        torch.load, nn.Module.load_state_dict, ref_sf.SlowFast.load_weight = real_load, real_lsd, real_sf_lw
     return m.eval()
 
 
@@ -75,6 +77,25 @@ def _save(case, **arrs):
     path = os.path.join(GOLD, case + ".npz")
     np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
     print("  wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def _feat_fixture(feats, max_elems=1 << 15):
+    """Feature maps are too big to commit whole: keep every stride-th element of the flattened tensor
+    (stride prime to the innermost dims so samples wander over all axes) plus mean / abs-max of the whole."""
+    out = {}
+    for i, f in enumerate(feats):
+        flat = f.detach().reshape(-1)
+        stride = max(1, flat.numel() // max_elems)
+        stride += 1 - stride % 2          # odd
+        while stride > 1 and any(d % stride == 0 for d in f.shape if d > 1):
+            stride += 2
+        k = "v%d" % (i + 1)
+        out[k + "_shape"] = np.array(f.shape)
+        out[k + "_stride"] = stride
+        out[k + "_sample"] = flat[::stride].clone()
+        out[k + "_mean"] = flat.double().mean().item()
+        out[k + "_absmax"] = flat.abs().max().item()
+    return out
 
 
 def _check_restatement(name, ref_out, ora_out, tol=2e-5):
@@ -106,8 +127,29 @@ def case_x3dl_backbone(size=64, seed=0):
         feats = ref([clips])
         ora = R.x3d_forward(sd, clips)
     _check_restatement("x3dl backbone", feats, ora)
-    _save("x3dl_backbone_%d" % size, seed=seed, size=size, batch=2, sd_crc=T.sd_checksum(sd),
-          **{"v%d" % (i + 1): f for i, f in enumerate(feats)})
+    _save("x3dl_backbone_%d" % size, seed=seed, size=size, batch=2, sd_crc=T.sd_checksum(sd), **_feat_fixture(feats))
+
+
+def case_slowfast_backbone(size=64, seed=0):
+    from mspi_amd.backbones.sf import SlowFast
+    from mspi_amd.config import cfg as pcfg
+    prod = T.seeded(lambda: SlowFast(pcfg.MODEL.SLOWFAST.PATH_CFG), seed)
+    sd = prod.state_dict()
+    rcfg = rh.with_config("slowfast4x16")
+    from backbones.sf import SlowFast as RefSF
+    ref = RefSF(path_to_config=rcfg.MODEL.SLOWFAST.PATH_CFG).eval()
+    ref.load_state_dict(sd, strict=True)
+    clips, _ = T.synth_inputs(2, 16, size, size, seed=seed)
+    x = R.pack_clips("slowfast4x16", clips)
+    with torch.no_grad():
+        feats = ref(x)
+        ora = R.slowfast_forward(sd, x)
+    _check_restatement("slowfast backbone", feats, ora)
+    _save("slowfast_backbone_%d" % size, seed=seed, size=size, batch=2, sd_crc=T.sd_checksum(sd), **_feat_fixture(feats))
+
+
+def case_av_slowfast_64():
+    _model_case("slowfast4x16", "AudioVisualSaliencyModel", 64, 2, 111, 0, "av_slowfast_64")
 
 
 def case_resnet18_audio(seed=0):

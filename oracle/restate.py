@@ -110,6 +110,37 @@ def x3d_forward(sd, clips, prefix=""):
     return feats
 
 
+# ------------------------------------------------------------------------------- SlowFast
+def basic_stem(sd, p, x):
+    """SlowFast/stem_helper.py:128-204: conv -> BN -> ReLU -> maxpool (1,3,3)/(1,2,2)."""
+    k = sd[p + ".conv.weight"].shape
+    x = F.relu(_bn(sd, p + ".bn", _conv3(sd, p + ".conv", x, (1, 2, 2), (k[2] // 2, k[3] // 2, k[4] // 2)), 1e-5))
+    return F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+
+
+def fuse_fast_to_slow(sd, p, xs, xf, alpha):
+    """backbones/sf.py:101-159."""
+    k = sd[p + ".conv_f2s.weight"].shape[2]
+    f = F.relu(_bn(sd, p + ".bn", _conv3(sd, p + ".conv_f2s", xf, (alpha, 1, 1), (k // 2, 0, 0)), 1e-5))
+    return torch.cat([xs, f], 1)
+
+
+def slowfast_forward(sd, x, prefix="", alpha=4):
+    """backbones/sf.py:360-385; features = slow pathway after s2/s3/s4 fusion and after s5."""
+    p = prefix
+    xs, xf = basic_stem(sd, p + "s1.pathway0_stem", x[0]), basic_stem(sd, p + "s1.pathway1_stem", x[1])
+    xs = fuse_fast_to_slow(sd, p + "s1_fuse", xs, xf, alpha)
+    feats = []
+    for i, s in enumerate(("s2", "s3", "s4", "s5")):
+        stride = 1 if i == 0 else 2
+        xs = res_stage(sd, p + s, xs, 0, stride, bottleneck_transform)
+        if i < 3:
+            xf = res_stage(sd, p + s, xf, 1, stride, bottleneck_transform)
+            xs = fuse_fast_to_slow(sd, p + s + "_fuse", xs, xf, alpha)
+        feats.append(xs)
+    return feats
+
+
 # ------------------------------------------------------------------------------- audio ResNet-18
 def resnet18_forward(sd, x, prefix=""):
     """backbones/resnet.py:57-143 (1-channel stem, BasicBlock x [2,2,2,2], returns layer4 map)."""
@@ -316,6 +347,7 @@ def pack_clips(name, clips):
 
 BACKBONES = {}  # name -> fn(sd, packed_clips, prefix) -> [v1..v4]; filled below and by restate_tx.py
 BACKBONES["x3dl"] = lambda sd, x, prefix: x3d_forward(sd, x[0], prefix)
+BACKBONES["slowfast4x16"] = lambda sd, x, prefix: slowfast_forward(sd, x, prefix)
 
 
 def audio_visual_forward(sd, clips, audios, name, lateral_bool, lateral_stride, num_frames=16):

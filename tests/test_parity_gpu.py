@@ -30,12 +30,23 @@ def test_x3dl_backbone_vs_golden(dev, golden_dir):
     m = T.seeded(lambda: X3D(cfg.MODEL.X3D.PATH_CFG), int(g["seed"])).to(dev)
     clips, _ = T.synth_inputs(int(g["batch"]), 16, int(g["size"]), int(g["size"]), seed=int(g["seed"]), device=dev)
     feats = m([clips])
-    assert [tuple(f.shape) for f in feats] == [g["v%d" % i].shape for i in (1, 2, 3, 4)]
     for i, f in enumerate(feats):
-        assert f.dtype == torch.float32 and _relerr(f, g["v%d" % (i + 1)]) < 1e-4, "v%d" % (i + 1)
+        assert f.dtype == torch.float32 and T.feature_error(f, g, "v%d" % (i + 1)) < 1e-4, "v%d" % (i + 1)
     # permuted-batch equivariance: clips are independent units (what lets the batch shard over GPUs)
     f2 = m([clips.flip(0)])
-    assert _relerr(f2[3].flip(0), g["v4"]) < 1e-4
+    assert T.feature_error(f2[3].flip(0), g, "v4") < 1e-4
+
+
+def test_slowfast_backbone_vs_golden(dev, golden_dir):
+    from mspi_amd.backbones.sf import SlowFast
+    from mspi_amd.config import cfg
+    from oracle import restate as R
+    g = _g(golden_dir, "slowfast_backbone_64")
+    m = T.seeded(lambda: SlowFast(cfg.MODEL.SLOWFAST.PATH_CFG), int(g["seed"])).to(dev)
+    clips, _ = T.synth_inputs(int(g["batch"]), 16, int(g["size"]), int(g["size"]), seed=int(g["seed"]), device=dev)
+    feats = m(R.pack_clips("slowfast4x16", clips))
+    for i, f in enumerate(feats):
+        assert T.feature_error(f, g, "v%d" % (i + 1)) < 1e-4, "v%d" % (i + 1)
 
 
 @pytest.mark.parametrize("wa", [111, 300])
@@ -57,10 +68,10 @@ def _build(g, name, cls, dev):
     return cfg, m.to(dev), clips, audio
 
 
-@pytest.mark.parametrize("case", ["av_x3dl_64", "av_x3dl_224"])
-def test_audio_visual_model_vs_golden(dev, golden_dir, case):
+@pytest.mark.parametrize("case,name", [("av_x3dl_64", "x3dl"), ("av_x3dl_224", "x3dl"), ("av_slowfast_64", "slowfast4x16")])
+def test_audio_visual_model_vs_golden(dev, golden_dir, case, name):
     g = _g(golden_dir, case)
-    cfg, m, clips, audio = _build(g, "x3dl", "AudioVisualSaliencyModel", dev)
+    cfg, m, clips, audio = _build(g, name, "AudioVisualSaliencyModel", dev)
     out, loss = m(clips, audio)
     assert tuple(out.shape) == g["out"].shape
     err = (out.cpu() - torch.as_tensor(g["out"])).abs().max().item()
