@@ -410,8 +410,7 @@ class _SaliencyBase(HipModule):
     def _pack_clips(self, clips):
         name = self.cfg.MODEL.MOTION_ENCODER
         if name == "slowfast4x16":  # model/model_utils.py:521-524: slow pathway = frames 0, 4, 12, last
-            idx = torch.tensor([0, 4, 12, clips.shape[2] - 1], device=clips.device)
-            return [clips.index_select(2, idx), clips]
+            return [torch.stack([clips[:, :, 0], clips[:, :, 4], clips[:, :, 12], clips[:, :, -1]], dim=2), clips]
         if "swin" in name:
             return clips
         return [clips]
