@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel timing table to stderr")
+    ap.add_argument("--kernel-detail", type=int, default=0, help="also print the N slowest individual launches")
     return ap.parse_args()
 
 
@@ -184,6 +185,15 @@ def main():
             for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
                 sys.stderr.write("%-28s calls %5d  %8.3f ms/step (%4.1f%%)  %7.2f TFLOP/s  %7.1f GB/s (algorithmic)\n" % (
                     k, d["calls"] // 3, d["ms"] / 3, 100 * d["ms"] / tot, d["flops"] / d["ms"] / 1e9, d["bytes"] / d["ms"] / 1e6))
+        if args.kernel_detail:
+            agg = {}
+            for name, fl, by, e0, e1, det in prof.records:
+                a = agg.setdefault((name, det), [0, 0.0, fl, by])
+                a[0] += 1
+                a[1] += e0.elapsed_time(e1)
+            for (name, det), a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:args.kernel_detail]:
+                sys.stderr.write("  %-30s x%-3d %8.1f us/launch %7.1f TF/s %7.0f GB/s  %s\n" % (
+                    name, a[0] // 3, 1e3 * a[1] / a[0], a[2] / (a[1] / a[0]) / 1e9, a[3] / (a[1] / a[0]) / 1e6, det))
         kname, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
         tflops = d["flops"] / d["ms"] / 1e9
         gbs = d["bytes"] / d["ms"] / 1e6

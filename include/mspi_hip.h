@@ -40,6 +40,12 @@ enum {
 
 enum { MSPI_ACT_NONE = 0, MSPI_ACT_RELU = 1, MSPI_ACT_GELU = 2, MSPI_ACT_SIGMOID = 3, MSPI_ACT_SWISH = 4 };
 
+/* GEMM arithmetic.  F32: v_mfma_f32_32x32x2_f32 (exact fp32).  F16X3: every fp32 operand is split into
+ * hi + lo f16 halves (22 significand bits) and the product is formed as hi*hi + hi*lo + lo*hi by three
+ * v_mfma_f32_32x32x16_f16 with fp32 accumulation -- fp32-level accuracy (<= 2^-21 relative per product) on
+ * the 16x faster f16 matrix pipe.  Operands must satisfy |x| < 65504 and |w * w_scale| < 65504. */
+enum { MSPI_PREC_F32 = 0, MSPI_PREC_F16X3 = 1 };
+
 int mspi_version(void);
 const char* mspi_last_error(void);
 /* number of visible HIP devices whose arch is gfx950 (0 if none). */
@@ -73,6 +79,10 @@ typedef struct MspiConvDesc {
   int64_t ldw;                     /* weight row stride, >= kT*kH*kW*C, multiple of 4, zero padded */
   int64_t ldr;                     /* residual row stride (res != NULL) */
   int32_t act;                     /* MSPI_ACT_* applied last */
+  int32_t prec;                    /* MSPI_PREC_F32: w is float [Cout][ldw];
+                                      MSPI_PREC_F16X3: w is _Float16 [2][Cout][ldw] = hi/lo split of w*w_scale,
+                                      ldw % 32 == 0 (see below) */
+  float w_scale;                   /* F16X3: power-of-two pre-scale of the weights (undone in the epilogue) */
 } MspiConvDesc;
 
 int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float* w, const float* bias /*[Cout] or NULL*/,
@@ -80,13 +90,14 @@ int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float* w, const f
                   float* y, mspi_stream_t stream);
 
 /* Which kernel instantiation the calling thread's last mspi_conv_fwd launched:
- * (BM << 16) | (BN << 4) | loader (0 = 16-B vector gather, 1 = scalar gather).  For profiling. */
+ * (BM << 16) | (BN << 4) | (prec << 1) | loader (0 = 16-B vector gather, 1 = scalar gather).  For profiling. */
 int mspi_conv_last_config(void);
 
 /* ------------------------------------------------------------------------------------
  * Depthwise convolution, channels-last, bias (= folded BN) + activation fused; optional
- * per-(n,c) sums of the pre-activation output for squeeze-excite (atomics into `pool`,
- * which the caller zeroes).
+ * per-(n,c) PARTIAL sums of the pre-activation output for squeeze-excite: pool is
+ * [N][mspi_dwconv_pool_rows(d)][C], one row per workgroup, written (not accumulated) in a
+ * fixed order -- no atomics, bitwise reproducible; mspi_se_gate reduces the rows.
  * Replaces: X3D `b` 3x3x3 (SlowFast/resnet_helper.py:310-319) + b_bn (+ Swish :76-103),
  *   X3D stem (5,1,1) (SlowFast/stem_helper.py:270-283), ConvNextBlock.dwconv_t/dwconv_s
  *   (model/model_utils.py:321-322), MViT pool_q/k/v (backbones/MViT.py:1093-1133),
@@ -104,12 +115,15 @@ typedef struct MspiDwConvDesc {
 } MspiDwConvDesc;
 
 int mspi_dwconv_fwd(const MspiDwConvDesc* d, const float* x, const float* w, const float* bias,
-                    float* y, float* pool /*NULL or [N][C]*/, mspi_stream_t stream);
+                    float* y, float* pool /*NULL or [N][rows][C]*/, mspi_stream_t stream);
+/* partial-sum rows per sample that mspi_dwconv_fwd writes for this descriptor (-1: pooling unsupported) */
+int mspi_dwconv_pool_rows(const MspiDwConvDesc* d);
 
-/* Squeeze-excite gate: gate[n,c] = sigmoid(fc2(relu(fc1(pool[n,:] * inv_count))))
+/* Squeeze-excite gate: gate[n,c] = sigmoid(fc2(relu(fc1(inv_count * sum_r pool[n,r,:]))))
  * (SlowFast/resnet_helper.py:27-73).  w1 [F][C], b1 [F], w2 [C][F], b2 [C]. */
-int mspi_se_gate(const float* pool, float inv_count, const float* w1, const float* b1, const float* w2,
-                 const float* b2, float* gate, int32_t N, int32_t C, int32_t F, mspi_stream_t stream);
+int mspi_se_gate(const float* pool, int32_t rows, float inv_count, const float* w1, const float* b1,
+                 const float* w2, const float* b2, float* gate, int32_t N, int32_t C, int32_t F,
+                 mspi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the C columns of each row, one wavefront per row:

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmspi_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_SWISH = range(5)
+PREC_F32, PREC_F16X3 = 0, 1
 
 
 class MspiError(RuntimeError):
@@ -27,6 +28,8 @@ class ConvDesc(C.Structure):
         ("Cout", C.c_int32),
         ("ldy", C.c_int64), ("ldw", C.c_int64), ("ldr", C.c_int64),
         ("act", C.c_int32),
+        ("prec", C.c_int32),
+        ("w_scale", C.c_float),
     ]
 
 
@@ -62,7 +65,8 @@ _SIGNATURES = {
     "mspi_conv_last_config": (C.c_int, []),
     "mspi_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "mspi_dwconv_fwd": (C.c_int, [C.POINTER(DwConvDesc), _P, _P, _P, _P, _P, _P]),
-    "mspi_se_gate": (C.c_int, [_P, C.c_float, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "mspi_dwconv_pool_rows": (C.c_int, [C.POINTER(DwConvDesc)]),
+    "mspi_se_gate": (C.c_int, [_P, C.c_int32, C.c_float, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mspi_layernorm_fwd": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P, _P, C.c_float, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mspi_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),

@@ -67,15 +67,10 @@ class X3D(HipModule):
         """x: [clips] with clips [N,3,T,H,W] fp32 on the GPU (any strides).  Returns 4 CL features."""
         self._check_eval()
         clips = x[0] if isinstance(x, (list, tuple)) else x
-        N = clips.shape[0]
-        stages = self._stages()
-        scratch = torch.zeros(N * sum(s.se_floats() for s in stages), dtype=torch.float32, device=clips.device)
         y = self.s1.run([clips])
-        feats, off = [], 0
-        for s in stages:
-            n = N * s.se_floats()
-            y = s.run(y, scratch[off: off + n])
-            off += n
+        feats = []
+        for s in self._stages():
+            y = s.run(y)
             feats.append(y[0])
         return feats
 

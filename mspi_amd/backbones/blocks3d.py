@@ -144,14 +144,13 @@ class X3DTransform(HipModule):
                         E._pad_vec(self.se.fc2.bias, cs_mid))
         return pk
 
-    def run(self, x, res, scratch, out=None):
-        """res: skip tensor added before the final ReLU; scratch: zeroed [N, C_mid_stored] pool slab or None."""
+    def run(self, x, res, out=None):
+        """res: skip tensor added before the final ReLU."""
         pk = self.pk
         t = E.conv(x, pk["a"])
         if "se" in pk:
-            u = E.dwconv(t, pk["b"], pool=scratch)
-            gate = torch.empty_like(scratch)
-            E.se_gate(scratch, 1.0 / (u.T * u.H * u.W), *pk["se"], gate)
+            u, part = E.dwconv(t, pk["b"], pool=True)
+            gate = E.se_gate(part, 1.0 / (u.T * u.H * u.W), *pk["se"])
             return E.conv(u, pk["c"], res=res, gate=gate, out=out)
         u = E.dwconv(t, pk["b"])
         return E.conv(u, pk["c"], res=res, out=out)
@@ -177,7 +176,7 @@ class BottleneckTransform(HipModule):
         return {n: E.pack_conv(c.weight, None, bn, c.stride, c.padding, E.ACT_RELU, cin_stored=E.rup4(c.in_channels))
                 for n, c, bn in (("a", self.a, self.a_bn), ("b", self.b, self.b_bn), ("c", self.c, self.c_bn))}
 
-    def run(self, x, res, scratch=None, out=None):
+    def run(self, x, res, out=None):
         pk = self.pk
         return E.conv(E.conv(E.conv(x, pk["a"]), pk["b"]), pk["c"], res=res, out=out)
 
@@ -203,13 +202,9 @@ class ResBlock(HipModule):
                                cin_stored=E.rup4(c.in_channels))
         return None
 
-    def se_width(self):
-        b2 = self.branch2
-        return E.rup4(b2.a.out_channels) if hasattr(b2, "se") else 0
-
-    def run(self, x, scratch=None, out=None):
+    def run(self, x, out=None):
         skip = E.conv(x, self.pk) if self.pk is not None else x
-        return self.branch2.run(x, skip, scratch, out=out)
+        return self.branch2.run(x, skip, out=out)
 
 
 class ResStage(HipModule):
@@ -233,26 +228,17 @@ class ResStage(HipModule):
     def blocks(self, p):
         return [getattr(self, "pathway{}_res{}".format(p, i)) for i in range(self.num_blocks[p])]
 
-    def se_floats(self, p=0):
-        return sum(b.se_width() for b in self.blocks(p))
-
-    def run(self, xs, scratch=None, outs=None, pathways=None):
-        """scratch: zeroed flat tensor with N*se_floats() floats (X3D only).  outs[p]: where pathway p's
-        last block writes (a channel slice of a concat buffer).  pathways: subset to compute."""
+    def run(self, xs, outs=None, pathways=None):
+        """outs[p]: where pathway p's last block writes (a channel slice of a concat buffer).
+        pathways: subset to compute."""
         out = []
         for p in range(self.num_pathways):
             if pathways is not None and p not in pathways:
                 out.append(None)
                 continue
             x = xs[p]
-            off = 0
             blocks = self.blocks(p)
             for bi, b in enumerate(blocks):
-                w = b.se_width()
-                slab = None
-                if w:
-                    slab = scratch[off: off + x.N * w].view(x.N, w)
-                    off += x.N * w
-                x = b.run(x, slab, out=outs[p] if (outs is not None and bi == len(blocks) - 1) else None)
+                x = b.run(x, out=outs[p] if (outs is not None and bi == len(blocks) - 1) else None)
             out.append(x)
         return out

@@ -15,6 +15,19 @@
 namespace mspi {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+
+// Precision modes.
+//  PREC_F32   : v_mfma_f32_32x32x2_f32 on fp32 operands (exact fp32 fmaf chain).
+//  PREC_F16X3 : fp32-accurate product on the 16x faster f16 matrix pipe.  Every operand is split
+//               x = hi + lo with hi = f16(x), lo = f16(x - hi) (22 significand bits together) and
+//               the product is accumulated in fp32 as hi*hi + hi*lo + lo*hi by three
+//               v_mfma_f32_32x32x16_f16 (the dropped lo*lo term is 2^-22 relative; f16xf16
+//               products are exact in fp32).  Weights are split once at pack time (pre-scaled by a
+//               power of two so their lo part stays a normal f16); activations are split while they
+//               are staged into LDS.
+enum { PREC_F32 = 0, PREC_F16X3 = 1 };
 
 struct ConvArgs {
   const float* x;
@@ -32,14 +45,16 @@ struct ConvArgs {
   int M, K;
   int rows_per_sample;
   int tiles_n, nblocks;
+  float out_scale;  // F16X3: 1 / (power-of-two weight pre-scale), applied to the accumulator
 };
 
 constexpr int BK = 32;
 constexpr int LDK = 36;  // padded LDS row (floats): 144 B keeps 16-B alignment, kills b128 conflicts
+constexpr int LDH = 40;  // F16X3: padded LDS row (halves): 80 B rows -> 16 distinct 16-B slots per b128 lane group
 
 enum { LOAD_V4 = 0, LOAD_S = 1 };
 
-template <int BM, int BN, int WM, int WN, int LOADER>
+template <int BM, int BN, int WM, int WN, int LOADER, int PREC>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
   constexpr int TM = BM / (WM * 32);
   constexpr int TN = BN / (WN * 32);
@@ -47,9 +62,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
   constexpr int BR = BN / 32;  // B rows staged per thread
   static_assert(WM * WN == 4, "4 waves per workgroup");
 
-  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+  // F32: A|B tiles of floats, rows LDK.  F16X3: A_hi|A_lo|B_hi|B_lo tiles of halves, rows LDH (same bytes/row+pad).
+  __shared__ __attribute__((aligned(16))) float smem[PREC == PREC_F32 ? (BM + BN) * LDK : (BM + BN) * LDH];
   float* As = smem;
   float* Bs = smem + BM * LDK;
+  _Float16* Ah = reinterpret_cast<_Float16*>(smem);
+  _Float16* Al = Ah + BM * LDH;
+  _Float16* Bh = Al + BM * LDH;
+  _Float16* Bl = Bh + BN * LDH;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -100,6 +120,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
     b_ok[i] = n < p.Cout;
     b_ptr[i] = p.w + (long)(b_ok[i] ? n : 0) * p.ldw;
   }
+  // F16X3 weights: [2][Cout][ldw] halves (hi plane, lo plane); a thread stages 16-B segments
+  // (8 halves) seg = tid&3 of rows (tid>>2) + 64*i.
+  constexpr int HB = (BN * 4 + 255) / 256;  // 16-B segments per thread per plane
+  const _Float16* wh = reinterpret_cast<const _Float16*>(p.w);
+  const long wplane = (long)p.Cout * p.ldw;
+  const int hseg = tid & 3, hrow = tid >> 2;
 
   // ---- k cursor of this thread's float4 (V4 loader): (tap, c) and tap -> (dt,dh,dw) ----
   int kc = kv * 4, ktap = 0, kdt = 0, kdh = 0, kdw = 0;
@@ -115,15 +141,31 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
   const int ntaps = p.kT * p.kH * p.kW;
 
   float4 ra[AR], rb[BR];
+  uint4 rbh[HB], rbl[HB];
 
   auto load_tiles = [&](int k0) {
     const int k = k0 + kv * 4;
-    // B (weights): rows are zero padded to ldw (multiple of 4)
+    if (PREC == PREC_F32) {
+      // B (weights): rows are zero padded to ldw (multiple of 4)
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b_ok[i] && k < p.ldw) v = *reinterpret_cast<const float4*>(b_ptr[i] + k);
-      rb[i] = v;
+      for (int i = 0; i < BR; ++i) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b_ok[i] && k < p.ldw) v = *reinterpret_cast<const float4*>(b_ptr[i] + k);
+        rb[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < HB; ++i) {
+        const int r = hrow + 64 * i, n = n0 + r;
+        uint4 h = make_uint4(0u, 0u, 0u, 0u), l = h;
+        if (r < BN && n < p.Cout) {   // ldw is a multiple of BK: no k guard
+          const _Float16* q = wh + (long)n * p.ldw + k0 + hseg * 8;
+          h = *reinterpret_cast<const uint4*>(q);
+          l = *reinterpret_cast<const uint4*>(q + wplane);
+        }
+        rbh[i] = h;
+        rbl[i] = l;
+      }
     }
     if (LOADER == LOAD_V4) {
       const bool kin = ktap < ntaps;
@@ -197,32 +239,82 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
 
   load_tiles(0);
   for (int k0 = 0; k0 < Kloop; k0 += BK) {
+    if (PREC == PREC_F32) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i)
-      *reinterpret_cast<float4*>(&As[(rbase + 32 * i) * LDK + kv * 4]) = ra[i];
+      for (int i = 0; i < AR; ++i)
+        *reinterpret_cast<float4*>(&As[(rbase + 32 * i) * LDK + kv * 4]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < BR; ++i)
-      *reinterpret_cast<float4*>(&Bs[(rbase + 32 * i) * LDK + kv * 4]) = rb[i];
+      for (int i = 0; i < BR; ++i)
+        *reinterpret_cast<float4*>(&Bs[(rbase + 32 * i) * LDK + kv * 4]) = rb[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        v4h hi, lo;
+        hi[0] = (_Float16)ra[i].x; hi[1] = (_Float16)ra[i].y; hi[2] = (_Float16)ra[i].z; hi[3] = (_Float16)ra[i].w;
+        lo[0] = (_Float16)(ra[i].x - (float)hi[0]);
+        lo[1] = (_Float16)(ra[i].y - (float)hi[1]);
+        lo[2] = (_Float16)(ra[i].z - (float)hi[2]);
+        lo[3] = (_Float16)(ra[i].w - (float)hi[3]);
+        *reinterpret_cast<v4h*>(&Ah[(rbase + 32 * i) * LDH + kv * 4]) = hi;
+        *reinterpret_cast<v4h*>(&Al[(rbase + 32 * i) * LDH + kv * 4]) = lo;
+      }
+#pragma unroll
+      for (int i = 0; i < HB; ++i) {
+        const int r = hrow + 64 * i;
+        if (r < BN) {
+          *reinterpret_cast<uint4*>(&Bh[r * LDH + hseg * 8]) = rbh[i];
+          *reinterpret_cast<uint4*>(&Bl[r * LDH + hseg * 8]) = rbl[i];
+        }
+      }
+    }
     __syncthreads();
     if (k0 + BK < Kloop) load_tiles(k0 + BK);  // next tile's loads fly under the MFMAs
+    if (PREC == PREC_F32) {
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      float4 fa[TM], fb[TN];
+      for (int kk = 0; kk < BK / 8; ++kk) {
+        float4 fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        fa[i] = *reinterpret_cast<const float4*>(&As[((wm * TM + i) * 32 + li) * LDK + kk * 8 + lh * 4]);
+        for (int i = 0; i < TM; ++i)
+          fa[i] = *reinterpret_cast<const float4*>(&As[((wm * TM + i) * 32 + li) * LDK + kk * 8 + lh * 4]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        fb[j] = *reinterpret_cast<const float4*>(&Bs[((wn * TN + j) * 32 + li) * LDK + kk * 8 + lh * 4]);
+        for (int j = 0; j < TN; ++j)
+          fb[j] = *reinterpret_cast<const float4*>(&Bs[((wn * TN + j) * 32 + li) * LDK + kk * 8 + lh * 4]);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+    } else {
+      // 32x32x16 f16: lane (i = lane&31, h = lane>>5) holds A[i][8h..8h+7] / B[8h..8h+7][j] of the 16-deep step
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        v8h ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int o = ((wm * TM + i) * 32 + li) * LDH + kk * 16 + lh * 8;
+          ah[i] = *reinterpret_cast<const v8h*>(&Ah[o]);
+          al[i] = *reinterpret_cast<const v8h*>(&Al[o]);
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+          const int o = ((wn * TN + j) * 32 + li) * LDH + kk * 16 + lh * 8;
+          bh[j] = *reinterpret_cast<const v8h*>(&Bh[o]);
+          bl[j] = *reinterpret_cast<const v8h*>(&Bl[o]);
         }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
     }
     __syncthreads();
   }
@@ -240,7 +332,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
       for (int r = 0; r < 16; ++r) {
         const int row = rb0 + (r & 3) + 8 * (r >> 2);
         if (row < p.M) {
-          float v = acc[i][j][r] + bv;
+          float v = (PREC == PREC_F32 ? acc[i][j][r] : acc[i][j][r] * p.out_scale) + bv;
           if (p.res) v += p.res[(long)row * p.ldr + col];
           p.y[(long)row * p.ldy + col] = act_apply(v, p.act);
         }
@@ -250,11 +342,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
 }
 
 template <int BM, int BN, int WM, int WN>
-static void launch_cfg(const ConvArgs& a, bool v4, hipStream_t s) {
-  if (v4)
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, LOAD_V4>), dim3(a.nblocks), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, LOAD_S>), dim3(a.nblocks), dim3(256), 0, s, a);
+static void launch_cfg(const ConvArgs& a, bool v4, int prec, hipStream_t s) {
+  const dim3 g(a.nblocks), b(256);
+  if (prec == PREC_F32) {
+    if (v4) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, LOAD_V4, PREC_F32>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, LOAD_S, PREC_F32>), g, b, 0, s, a);
+  } else {
+    if (v4) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, LOAD_V4, PREC_F16X3>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, LOAD_S, PREC_F16X3>), g, b, 0, s, a);
+  }
 }
 
 }  // namespace mspi
@@ -278,7 +374,10 @@ extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float*
                "mspi_conv_fwd: output extent (%d,%d,%d) does not match formula (%d,%d,%d)", d->To, d->Ho, d->Wo, To,
                Ho, Wo);
   const long K = (long)d->kT * d->kH * d->kW * d->C;
+  MSPI_REQUIRE(d->prec == PREC_F32 || d->prec == PREC_F16X3, "mspi_conv_fwd: unknown precision mode %d", d->prec);
   MSPI_REQUIRE(d->ldw >= K && (d->ldw & 3) == 0 && aligned16(w), "mspi_conv_fwd: weight rows must be 16-B aligned, ldw >= K");
+  MSPI_REQUIRE(d->prec == PREC_F32 || ((d->ldw % BK) == 0 && d->w_scale > 0.f),
+               "mspi_conv_fwd: f16x3 weights need ldw %% 32 == 0 and a positive w_scale");
   MSPI_REQUIRE(d->ldy >= d->Cout, "mspi_conv_fwd: ldy < Cout");
   MSPI_REQUIRE(!res || d->ldr >= d->Cout, "mspi_conv_fwd: ldr < Cout");
   const long Ml = (long)d->N * To * Ho * Wo;
@@ -299,6 +398,7 @@ extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float*
   a.To = To; a.Ho = Ho; a.Wo = Wo; a.Cout = d->Cout;
   a.ldy = d->ldy; a.ldw = d->ldw; a.ldr = d->ldr; a.act = d->act;
   a.M = (int)Ml; a.K = (int)K; a.rows_per_sample = To * Ho * Wo;
+  a.out_scale = d->prec == PREC_F16X3 ? 1.0f / d->w_scale : 1.0f;
 
   // tile choice: least padded work, with a penalty for narrow tiles (more LDS traffic per
   // MFMA) and for grids too small to fill 256 CUs.
@@ -321,12 +421,12 @@ extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float*
   MSPI_REQUIRE(nb < (1L << 31), "mspi_conv_fwd: grid too large");
   a.nblocks = (int)nb;
   hipStream_t s = (hipStream_t)stream;
-  g_last_cfg = (BMs << 16) | (BNs << 4) | (v4 ? 0 : 1);
+  g_last_cfg = (BMs << 16) | (BNs << 4) | (d->prec << 1) | (v4 ? 0 : 1);
   switch (best) {
-    case 0: launch_cfg<128, 128, 2, 2>(a, v4, s); break;
-    case 1: launch_cfg<128, 64, 2, 2>(a, v4, s); break;
-    case 2: launch_cfg<128, 32, 4, 1>(a, v4, s); break;
-    default: launch_cfg<64, 64, 2, 2>(a, v4, s); break;
+    case 0: launch_cfg<128, 128, 2, 2>(a, v4, d->prec, s); break;
+    case 1: launch_cfg<128, 64, 2, 2>(a, v4, d->prec, s); break;
+    case 2: launch_cfg<128, 32, 4, 1>(a, v4, d->prec, s); break;
+    default: launch_cfg<64, 64, 2, 2>(a, v4, d->prec, s); break;
   }
   return check_launch("mspi_conv_fwd");
 }

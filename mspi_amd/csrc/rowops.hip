@@ -66,16 +66,40 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------ SE gate
-// One workgroup per sample: fc1 (C->F) by wavefront-reduced dot products, ReLU, fc2, sigmoid.
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ pool, float inv_count,
+// One workgroup per sample.  pool holds `rows` partial sums per channel (one per dwconv block, fixed order):
+// they are summed here in a fixed order too (thread groups over row ranges, then a serial combine), so the
+// squeeze-excite path is bitwise reproducible.  Then fc1 (C->F) by wavefront-reduced dots, ReLU, fc2, sigmoid.
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ pool, int rows, float inv_count,
                                                       const float* __restrict__ w1, const float* __restrict__ b1,
                                                       const float* __restrict__ w2, const float* __restrict__ b2,
                                                       float* __restrict__ gate, int C, int F) {
-  extern __shared__ float sm[];  // [C] means, [F] hidden
-  float* mean = sm;
-  float* hid = sm + C;
+  extern __shared__ float sm[];  // [G*C] partial sums, then [C] means, [F] hidden
   const int n = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += 256) mean[c] = pool[(long)n * C + c] * inv_count;
+  const int G = C <= 256 ? 256 / C : 1;   // row groups
+  float* part = sm;
+  float* mean = sm + G * C;
+  float* hid = mean + C;
+  const float* pb = pool + (long)n * rows * C;
+  if (G > 1) {
+    const int c = threadIdx.x % C, g = threadIdx.x / C;
+    if (g < G) {
+      float s = 0.f;
+      for (int r = g; r < rows; r += G) s += pb[(long)r * C + c];
+      part[g * C + c] = s;
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float s = 0.f;
+      for (int r = 0; r < rows; ++r) s += pb[(long)r * C + c];
+      part[c] = s;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += part[g * C + c];
+    mean[c] = s * inv_count;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int f = wave; f < F; f += 4) {
@@ -259,12 +283,15 @@ extern "C" int mspi_layernorm_fwd(const float* x, int64_t ldx, int64_t sNx, floa
   return check_launch("mspi_layernorm_fwd");
 }
 
-extern "C" int mspi_se_gate(const float* pool, float inv_count, const float* w1, const float* b1, const float* w2,
-                            const float* b2, float* gate, int32_t N, int32_t C, int32_t F, mspi_stream_t stream) {
+extern "C" int mspi_se_gate(const float* pool, int32_t rows, float inv_count, const float* w1, const float* b1,
+                            const float* w2, const float* b2, float* gate, int32_t N, int32_t C, int32_t F,
+                            mspi_stream_t stream) {
   MSPI_REQUIRE(pool && w1 && b1 && w2 && b2 && gate, "mspi_se_gate: null argument");
-  MSPI_REQUIRE(N > 0 && C > 0 && F > 0 && (size_t)(C + F) * 4 <= 64 * 1024, "mspi_se_gate: bad extent");
-  hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), (size_t)(C + F) * sizeof(float), (hipStream_t)stream, pool,
-                     inv_count, w1, b1, w2, b2, gate, C, F);
+  const int G = C <= 256 ? 256 / C : 1;
+  const size_t lds = (size_t)(G * C + C + F) * sizeof(float);
+  MSPI_REQUIRE(N > 0 && rows > 0 && C > 0 && F > 0 && lds <= 64 * 1024, "mspi_se_gate: bad extent");
+  hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), lds, (hipStream_t)stream, pool, rows, inv_count, w1, b1, w2,
+                     b2, gate, C, F);
   return check_launch("mspi_se_gate");
 }
 

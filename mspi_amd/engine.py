@@ -14,8 +14,13 @@ import math
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH, AttnDesc, ConvDesc, DwConvDesc,
-                   MspiError, check)
+from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH, PREC_F16X3, PREC_F32, AttnDesc, ConvDesc,
+                   DwConvDesc, MspiError, check)
+
+# GEMM arithmetic for every dense conv / Linear: "f16x3" (default; fp32-accurate split product on the f16 matrix
+# pipe, see include/mspi_hip.h) or "f32" (v_mfma_f32_32x32x2_f32).  Read when weights are packed.
+import os as _os
+DEFAULT_PREC = {"f32": PREC_F32, "f16x3": PREC_F16X3}[_os.environ.get("MSPI_GEMM_PREC", "f16x3")]
 
 __all__ = ["CL", "alloc", "pack_conv", "pack_dwconv", "PackedConv", "PackedDw", "conv", "dwconv", "maxpool",
            "layernorm", "attention", "upsample", "rowgate", "logsumexp_sub", "mean_rows", "neg_cosine",
@@ -33,7 +38,7 @@ class Profiler:
     active = None
 
     def __init__(self):
-        self.records = []   # (kernel_name, flops, bytes, start_event, end_event)
+        self.records = []   # (kernel_name, flops, bytes, start_event, end_event, detail)
 
     def __enter__(self):
         Profiler.active = self
@@ -45,7 +50,7 @@ class Profiler:
     def summary(self):
         """{kernel: dict(calls, ms, flops, bytes)} -- call after torch.cuda.synchronize()."""
         out = {}
-        for name, fl, by, e0, e1 in self.records:
+        for name, fl, by, e0, e1, _ in self.records:
             d = out.setdefault(name, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["calls"] += 1
             d["ms"] += e0.elapsed_time(e1)
@@ -55,10 +60,10 @@ class Profiler:
 
 
 class _Timed:
-    __slots__ = ("name", "flops", "bytes", "e0")
+    __slots__ = ("name", "flops", "bytes", "e0", "detail")
 
-    def __init__(self, name, flops=0.0, nbytes=0.0):
-        self.name, self.flops, self.bytes = name, flops, nbytes
+    def __init__(self, name, flops=0.0, nbytes=0.0, detail=""):
+        self.name, self.flops, self.bytes, self.detail = name, flops, nbytes, detail
 
     def __enter__(self):
         if Profiler.active is not None:
@@ -71,7 +76,7 @@ class _Timed:
         if p is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            p.records.append((self.name, self.flops, self.bytes, self.e0, e1))
+            p.records.append((self.name, self.flops, self.bytes, self.e0, e1, self.detail))
 
 
 def _stream():
@@ -161,11 +166,11 @@ def fold_bn(weight, bias, bn):
 
 
 class PackedConv:
-    __slots__ = ("w", "bias", "k", "stride", "pad", "cin", "cin_s", "cout", "cout_s", "ldw", "act")
+    __slots__ = ("w", "bias", "k", "stride", "pad", "cin", "cin_s", "cout", "cout_s", "ldw", "act", "prec", "w_scale")
 
 
 def pack_conv(weight, bias=None, bn=None, stride=(1, 1, 1), pad=(0, 0, 0), act=ACT_NONE, cin_stored=None,
-              out_scale=None, device=None):
+              out_scale=None, device=None, prec=None):
     """weight: [Co,Ci] (Linear), [Co,Ci,kh,kw] (2-D) or [Co,Ci,kt,kh,kw].  Result rows are
     [Co_s][ldw] with k = (kt,kh,kw,ci) ci fastest, Ci padded to cin_stored, Co to a multiple of 4."""
     w, b = fold_bn(weight, bias, bn)
@@ -182,14 +187,28 @@ def pack_conv(weight, bias=None, bn=None, stride=(1, 1, 1), pad=(0, 0, 0), act=A
     assert cin_s >= ci
     cout_s = rup4(co) if co > 1 else 1
     K = kt * kh * kw * cin_s
-    ldw = rup4(K)
+    prec = DEFAULT_PREC if prec is None else prec
+    ldw = rup4(K) if prec == PREC_F32 else (K + 31) // 32 * 32
     wp = torch.zeros(cout_s, kt, kh, kw, cin_s, dtype=torch.float32, device=w.device)
     wp[:co, :, :, :, :ci] = w.permute(0, 2, 3, 4, 1)
     wf = torch.zeros(cout_s, ldw, dtype=torch.float32, device=w.device)
     wf[:, :K] = wp.reshape(cout_s, K)
     p = PackedConv()
     dev = w.device if device is None else device
-    p.w = wf.to(dev).contiguous()
+    p.prec, p.w_scale = prec, 1.0
+    if prec == PREC_F16X3:
+        # power-of-two pre-scale puts max|w| in [2^13, 2^14): the lo halves of typical weights are normal f16
+        mx = float(wf.abs().max())
+        if not math.isfinite(mx):
+            raise MspiError("pack_conv: non-finite weights")
+        e = 0 if mx == 0.0 else max(-10, min(24, int(math.floor(math.log2(16384.0 / mx)))))
+        p.w_scale = float(2.0 ** e)
+        ws = wf * p.w_scale
+        hi = ws.to(torch.float16)
+        lo = (ws - hi.float()).to(torch.float16)
+        p.w = torch.stack([hi, lo]).to(dev).contiguous()
+    else:
+        p.w = wf.to(dev).contiguous()
     if b is None:
         p.bias = None
     else:
@@ -271,19 +290,23 @@ def conv(x, pk, out=None, res=None, gate=None, act=None):
     d.ldy, d.ldw = out.ld, pk.ldw
     d.ldr = res.ld if res is not None else 0
     d.act = pk.act if act is None else act
+    d.prec, d.w_scale = pk.prec, pk.w_scale
     if res is not None and (res.M != out.M or not res.dense):
         raise MspiError("conv: residual rows %d != output rows %d (or residual not dense)" % (res.M, out.M))
     M = N * To * Ho * Wo
     taps = pk.k[0] * pk.k[1] * pk.k[2]
     tm = _Timed("conv_gemm", 2.0 * M * taps * pk.cin * pk.cout,
-                4.0 * (N * T * H * W * pk.cin + M * pk.cout * (2 if res is not None else 1) + pk.cout * taps * pk.cin))
+                4.0 * (N * T * H * W * pk.cin + M * pk.cout * (2 if res is not None else 1) + pk.cout * taps * pk.cin),
+                "M=%d K=%d(%dx%d) N=%d s=%s%s%s" % (M, taps * pk.cin, taps, pk.cin, pk.cout, pk.stride,
+                                                  " +res" if res is not None else "", " +gate" if gate is not None else ""))
     with tm:
         check(lib.mspi_conv_fwd(C.byref(d), xptr, pk.w.data_ptr(), pk.bias.data_ptr() if pk.bias is not None else None,
                                 res.ptr if res is not None else None, gate.data_ptr() if gate is not None else None,
                                 out.ptr, _stream()), "mspi_conv_fwd")
         if Profiler.active is not None:
             c = lib.mspi_conv_last_config()
-            tm.name = "conv_gemm<%d,%d,%s>" % (c >> 16, (c >> 4) & 0xFFF, "s" if c & 1 else "v4")
+            tm.name = "conv_gemm<%d,%d,%s,%s>" % (c >> 16, (c >> 4) & 0xFFF, "s" if c & 1 else "v4",
+                                                  "f16x3" if (c >> 1) & 1 else "f32")
     return out
 
 
@@ -299,7 +322,8 @@ def _dw_desc(x, k, s, p, out_ld):
     return d
 
 
-def dwconv(x, pk, out=None, pool=None, act=None):
+def dwconv(x, pk, out=None, pool=False, act=None):
+    """pool=True (X3D squeeze-excite): also returns the [N, rows, C] partial sums of the pre-activation output."""
     lib = _lib.load()
     _need_gpu(x.buf)
     if x.Cs != pk.c_s:
@@ -309,11 +333,18 @@ def dwconv(x, pk, out=None, pool=None, act=None):
         out = alloc(x.N, To, Ho, Wo, x.C, x.buf.device)
     d = _dw_desc(x, pk.k, pk.stride, pk.pad, out.ld)
     d.act = pk.act if act is None else act
+    part = None
+    if pool:
+        rows = lib.mspi_dwconv_pool_rows(C.byref(d))
+        if rows <= 0:
+            raise MspiError("dwconv: squeeze-excite pooling is not supported for kernel %s stride %s" % (pk.k, pk.stride))
+        part = torch.empty(x.N, rows, pk.c_s, dtype=torch.float32, device=x.buf.device)
     taps = pk.k[0] * pk.k[1] * pk.k[2]
-    with _Timed("dwconv_pool" if pool is not None else "dwconv", 2.0 * out.M * taps * pk.c, 4.0 * (x.M + out.M) * pk.c):
+    with _Timed("dwconv_pool" if pool else "dwconv", 2.0 * out.M * taps * pk.c, 4.0 * (x.M + out.M) * pk.c,
+                "in=%s C=%d k=%s s=%s" % ((x.N, x.T, x.H, x.W), pk.c, pk.k, pk.stride)):
         check(lib.mspi_dwconv_fwd(C.byref(d), x.ptr, pk.w.data_ptr(), pk.bias.data_ptr(), out.ptr,
-                                  pool.data_ptr() if pool is not None else None, _stream()), "mspi_dwconv_fwd")
-    return out
+                                  part.data_ptr() if pool else None, _stream()), "mspi_dwconv_fwd")
+    return (out, part) if pool else out
 
 
 def maxpool(x, k, s, p, out=None):
@@ -329,10 +360,13 @@ def maxpool(x, k, s, p, out=None):
     return out
 
 
-def se_gate(pool, inv_count, w1, b1, w2, b2, gate):
+def se_gate(pool, inv_count, w1, b1, w2, b2, gate=None):
+    """pool: [N, rows, C] partial sums from dwconv(pool=True) -> gate [N, C]."""
     lib = _lib.load()
-    N, Cc = pool.shape
-    check(lib.mspi_se_gate(pool.data_ptr(), float(inv_count), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+    N, rows, Cc = pool.shape
+    if gate is None:
+        gate = torch.empty(N, Cc, dtype=torch.float32, device=pool.device)
+    check(lib.mspi_se_gate(pool.data_ptr(), rows, float(inv_count), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
                            b2.data_ptr(), gate.data_ptr(), N, Cc, w1.shape[0], _stream()), "mspi_se_gate")
     return gate
 
@@ -347,7 +381,7 @@ def layernorm(x, gamma, beta, eps, out=None, act=ACT_NONE, table=None):
     assert out.N == x.N and out.T * out.H * out.W == R and out.C == x.C
     P = 0 if table is None else table.shape[0]
     assert table is None or P == R
-    with _Timed("layernorm", 8.0 * x.M * x.C, 8.0 * x.M * x.C):
+    with _Timed("layernorm", 8.0 * x.M * x.C, 8.0 * x.M * x.C, "M=%d C=%d" % (x.M, x.C)):
         check(lib.mspi_layernorm_fwd(x.ptr, x.ld, x.sN, out.ptr, out.ld, out.sN, gamma.data_ptr(), beta.data_ptr(),
                                      float(eps), x.N, R, x.C, act, table.data_ptr() if table is not None else None,
                                      _stream()), "mspi_layernorm_fwd")

@@ -111,8 +111,12 @@ def test_pack_conv_folds_bn_and_orders_taps():
         bn.running_var.uniform_(0.5, 2)
         bn.weight.normal_()
         bn.bias.normal_()
-    pk = E.pack_conv(conv.weight, conv.bias, bn, cin_stored=8)
+    pk = E.pack_conv(conv.weight, conv.bias, bn, cin_stored=8, prec=E.PREC_F32)
     assert pk.w.shape == (12, 3 * 1 * 2 * 8) and pk.cout_s == 12 and pk.ldw % 4 == 0
+    ph = E.pack_conv(conv.weight, conv.bias, bn, cin_stored=8, prec=E.PREC_F16X3)
+    assert ph.w.dtype == torch.float16 and ph.w.shape == (2, 12, 64) and math.log2(ph.w_scale) % 1 == 0
+    rec = (ph.w[0].double() + ph.w[1].double()) / ph.w_scale          # hi + lo reproduces the fp32 weights to 2^-21
+    assert (rec[:, :48] - pk.w.double()).abs().max() <= 2.0 ** -20 * pk.w.abs().max()
     x = torch.randn(2, 6, 5, 4, 4)
     ref = bn(conv(x))
     # emulate the kernel's A row layout: (tap, ci) with ci fastest, channels padded to 8

@@ -47,7 +47,8 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("act", [0, 1, 2])
-def test_conv(dev, case, act):
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f16x3"])
+def test_conv(dev, case, act, prec):
     from mspi_amd import engine as E
     N, Cin, T, H, W, Cout, k, s, p, raw = case
     g = torch.Generator().manual_seed(hash(case) % 1000)
@@ -58,13 +59,28 @@ def test_conv(dev, case, act):
     res = torch.randn_like(ref)
     ref = ref + res
     ref = {0: ref, 1: F.relu(ref), 2: F.gelu(ref)}[act]
-    pk = E.pack_conv(w, b, None, s, p, act, cin_stored=Cin if raw else E.rup4(Cin), device=dev)
+    pk = E.pack_conv(w, b, None, s, p, act, cin_stored=Cin if raw else E.rup4(Cin), device=dev, prec=prec)
     xin = x.to(dev) if raw else _cl(x, dev)
     out = E.conv(xin, pk, res=_cl(res, dev))
     torch.cuda.synchronize()
     _close(out.as_ncdhw(Cout), ref, 2e-5, "conv %s" % (case,))
     if out.Cs > Cout:  # pad columns must hold act(0 + res_pad) = finite
         assert torch.isfinite(out.buf).all()
+
+
+def test_conv_f16x3_wide_dynamic_range(dev):
+    """The split product must stay fp32-accurate for operands spanning many binades (tiny and large
+    activations in one row, weights from 1e-4 to 10) -- plain f16 would be off by 1e-3 here."""
+    from mspi_amd import engine as E
+    g = torch.Generator().manual_seed(11)
+    M, K, Nn = 300, 416, 136
+    x = torch.randn(1, K, 1, 1, M, generator=g) * torch.logspace(-3, 2.5, K).view(1, K, 1, 1, 1)
+    w = torch.randn(Nn, K, 1, 1, 1, generator=g) * torch.logspace(-4, 1, Nn).view(Nn, 1, 1, 1, 1) / math.sqrt(K)
+    ref = F.conv3d(x.double(), w.double()).float()
+    out = E.conv(_cl(x, dev), E.pack_conv(w, device=dev, prec=1))
+    got = out.as_ncdhw(Nn).cpu()
+    rowscale = (x.abs().double().flatten(1, 3).transpose(1, 2) @ w.abs().double().flatten(1).t()).transpose(1, 2).view_as(ref)
+    assert ((got - ref).abs() / rowscale.float().clamp_min(1e-30)).max().item() < 3e-6   # ~fp32 dot-product error bound
 
 
 def test_conv_gate_and_slices(dev):
@@ -103,6 +119,8 @@ DW_CASES = [
     (1, 192, 2, 12, 13, (1, 7, 7), (1, 1, 1), (0, 3, 3)),
     (3, 96, 1, 14, 14, (1, 7, 7), (1, 1, 1), (0, 3, 3)),
     (2, 96, 4, 8, 8, (3, 3, 3), (1, 8, 8), (1, 1, 1)),
+    (1, 56, 3, 11, 13, (3, 3, 3), (1, 2, 2), (1, 1, 1)),   # odd extents: ragged strips, stride 2
+    (2, 432, 2, 7, 7, (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # C/4 = 108 > strips per block
 ]
 
 
@@ -118,10 +136,14 @@ def test_dwconv_pool_maxpool(dev, case):
     pk = E.pack_dwconv(w, b, None, s, p, E.ACT_SWISH, device=dev)
     out = E.dwconv(_cl(x, dev), pk)
     _close(out.as_ncdhw(C), ref * torch.sigmoid(ref), 2e-5, "dwconv swish")
-    pool = torch.zeros(N, E.rup4(C), device=dev)
-    out = E.dwconv(_cl(x, dev), pk, pool=pool, act=E.ACT_NONE)
+    out = E.dwconv(_cl(x, dev), pk, act=E.ACT_NONE)
     _close(out.as_ncdhw(C), ref, 2e-5, "dwconv")
-    _close(pool[:, :C], ref.sum((2, 3, 4)), 2e-5, "se pool sums")
+    if k[1] == k[2] and k[2] in (3, 7) and s[2] in (1, 2) and (k[2], s[2]) != (7, 2):
+        out, part = E.dwconv(_cl(x, dev), pk, pool=True, act=E.ACT_NONE)
+        _close(out.as_ncdhw(C), ref, 2e-5, "dwconv (pool)")
+        _close(part.sum(1)[:, :C], ref.sum((2, 3, 4)), 2e-5, "se pool partial sums")
+        out2, part2 = E.dwconv(_cl(x, dev), pk, pool=True, act=E.ACT_NONE)
+        assert torch.equal(part, part2) and torch.equal(out.buf, out2.buf)      # no atomics: bitwise reproducible
     if all(2 * pp <= kk for pp, kk in zip(p, k)):
         mp = E.maxpool(_cl(x, dev), k, s, p)
         _close(mp.as_ncdhw(C), F.max_pool3d(x, k, s, p), 0, "maxpool")
@@ -131,13 +153,13 @@ def test_se_gate(dev):
     from mspi_amd import engine as E
     g = torch.Generator().manual_seed(2)
     N, C, Fh = 3, 56, 8
-    pool = torch.randn(N, C, generator=g) * 50
-    w1, b1 = torch.randn(Fh, C, generator=g) / 7, torch.randn(Fh, generator=g)
-    w2, b2 = torch.randn(C, Fh, generator=g) / 3, torch.randn(C, generator=g)
-    ref = torch.sigmoid(F.linear(F.relu(F.linear(pool / 100.0, w1, b1)), w2, b2))
-    gate = torch.empty(N, C, device=dev)
-    E.se_gate(pool.to(dev), 1 / 100.0, w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), gate)
-    _close(gate, ref, 1e-5, "se gate")
+    for rows, C in ((37, 56), (5, 432), (700, 216)):
+        pool = torch.randn(N, rows, C, generator=g) * 50 / rows ** 0.5
+        w1, b1 = torch.randn(Fh, C, generator=g) / 7, torch.randn(Fh, generator=g)
+        w2, b2 = torch.randn(C, Fh, generator=g) / 3, torch.randn(C, generator=g)
+        ref = torch.sigmoid(F.linear(F.relu(F.linear(pool.sum(1) / 100.0, w1, b1)), w2, b2))
+        gate = E.se_gate(pool.to(dev), 1 / 100.0, w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev))
+        _close(gate, ref, 1e-5, "se gate")
 
 
 @pytest.mark.parametrize("C", [96, 512, 768, 3072])
