@@ -31,10 +31,23 @@ inline int check_launch(const char* what) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 rounding level): libm's erff inlines to
+// ~40 instructions per call site and GEMM epilogues have 64 of them.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  float y = fmaf(1.061405429f, t, -1.453152027f);
+  y = fmaf(y, t, 1.421413741f);
+  y = fmaf(y, t, -0.284496736f);
+  y = fmaf(y, t, 0.254829592f);
+  y = 1.f - y * t * __expf(-ax * ax);
+  return copysignf(y, x);
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
     case MSPI_ACT_RELU: return fmaxf(v, 0.f);
-    case MSPI_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));  // nn.GELU (erf form)
+    case MSPI_ACT_GELU: return 0.5f * v * (1.f + fast_erf(v * 0.70710678118654752440f));  // nn.GELU (erf form)
     case MSPI_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
     case MSPI_ACT_SWISH: return v / (1.f + __expf(-v));
     default: return v;

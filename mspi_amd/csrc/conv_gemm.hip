@@ -11,6 +11,7 @@
 // fragment reads (lane (i,h) takes k = 4h..4h+3 of row i: the MFMA K order is permuted
 // identically for A and B, which a dot product does not care about) are conflict-free.
 #include "common.h"
+#include <stdlib.h>
 
 namespace mspi {
 
@@ -55,21 +56,19 @@ constexpr int LDH = 40;  // F16X3: padded LDS row (halves): 80 B rows -> 16 dist
 enum { LOAD_V4 = 0, LOAD_S = 1 };
 
 template <int BM, int BN, int WM, int WN, int LOADER, int PREC>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvArgs p) {
+  constexpr int NT = WM * WN * 64;   // threads
+  constexpr int RP = NT / 8;         // tile rows staged per pass (8 threads x float4 cover the 32-float k chunk)
   constexpr int TM = BM / (WM * 32);
   constexpr int TN = BN / (WN * 32);
-  constexpr int AR = BM / 32;  // A rows staged per thread
-  constexpr int BR = BN / 32;  // B rows staged per thread
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int AR = BM / RP;        // A rows staged per thread
+  constexpr int BR = (BN + RP - 1) / RP;  // B rows staged per thread (F32)
+  static_assert(BM % RP == 0 && TM >= 1 && TN >= 1, "tile/wave shape");
 
   // F32: A|B tiles of floats, rows LDK.  F16X3: A_hi|A_lo|B_hi|B_lo tiles of halves, rows LDH (same bytes/row+pad).
-  __shared__ __attribute__((aligned(16))) float smem[PREC == PREC_F32 ? (BM + BN) * LDK : (BM + BN) * LDH];
-  float* As = smem;
-  float* Bs = smem + BM * LDK;
-  _Float16* Ah = reinterpret_cast<_Float16*>(smem);
-  _Float16* Al = Ah + BM * LDH;
-  _Float16* Bh = Al + BM * LDH;
-  _Float16* Bl = Bh + BN * LDH;
+  // Two LDS stages (one barrier per K step, global prefetch two tiles ahead).
+  constexpr int STAGE = PREC == PREC_F32 ? (BM + BN) * LDK : (BM + BN) * LDH;   // floats per stage
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -89,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int kv = tid & 7;      // which float4 of the 32-float k chunk
-  const int rbase = tid >> 3;  // 0..31
+  const int rbase = tid >> 3;  // 0..RP-1
 
   // ---- per-row gather state (fixed over the K loop) ----
   long a_off[AR];
@@ -97,7 +96,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
   bool a_ok[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    int m = m0 + rbase + 32 * i;
+    int m = m0 + rbase + RP * i;
     a_ok[i] = m < p.M;
     if (!a_ok[i]) m = 0;
     int wo = m % p.Wo;
@@ -116,13 +115,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
   bool b_ok[BR];
 #pragma unroll
   for (int i = 0; i < BR; ++i) {
-    int n = n0 + rbase + 32 * i;
-    b_ok[i] = n < p.Cout;
+    int n = n0 + rbase + RP * i;
+    b_ok[i] = n < p.Cout && rbase + RP * i < BN;
     b_ptr[i] = p.w + (long)(b_ok[i] ? n : 0) * p.ldw;
   }
   // F16X3 weights: [2][Cout][ldw] halves (hi plane, lo plane); a thread stages 16-B segments
   // (8 halves) seg = tid&3 of rows (tid>>2) + 64*i.
-  constexpr int HB = (BN * 4 + 255) / 256;  // 16-B segments per thread per plane
+  constexpr int HB = (BN * 4 + NT - 1) / NT;  // 16-B segments per thread per plane
+  constexpr int HR = NT / 4;                  // weight rows staged per pass
   const _Float16* wh = reinterpret_cast<const _Float16*>(p.w);
   const long wplane = (long)p.Cout * p.ldw;
   const int hseg = tid & 3, hrow = tid >> 2;
@@ -149,22 +149,22 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
       // B (weights): rows are zero padded to ldw (multiple of 4)
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (b_ok[i] && k < p.ldw) v = *reinterpret_cast<const float4*>(b_ptr[i] + k);
-        rb[i] = v;
+        // unconditional load from a always-valid address + select: a branch around the load would make
+        // hipcc wait vmcnt(0) per load and serialise the whole tile fetch
+        const bool ok = b_ok[i] && k < p.ldw;
+        const float4 v = *reinterpret_cast<const float4*>(ok ? b_ptr[i] + k : p.w);
+        rb[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < HB; ++i) {
-        const int r = hrow + 64 * i, n = n0 + r;
-        uint4 h = make_uint4(0u, 0u, 0u, 0u), l = h;
-        if (r < BN && n < p.Cout) {   // ldw is a multiple of BK: no k guard
-          const _Float16* q = wh + (long)n * p.ldw + k0 + hseg * 8;
-          h = *reinterpret_cast<const uint4*>(q);
-          l = *reinterpret_cast<const uint4*>(q + wplane);
-        }
-        rbh[i] = h;
-        rbl[i] = l;
+        const int r = hrow + HR * i, n = n0 + r;
+        const bool ok = r < BN && n < p.Cout;   // ldw is a multiple of BK: no k guard
+        const _Float16* q = wh + (ok ? (long)n * p.ldw + k0 + hseg * 8 : 0);
+        const uint4 h = *reinterpret_cast<const uint4*>(q);
+        const uint4 l = *reinterpret_cast<const uint4*>(q + wplane);
+        rbh[i] = ok ? h : make_uint4(0u, 0u, 0u, 0u);
+        rbl[i] = ok ? l : make_uint4(0u, 0u, 0u, 0u);
       }
     }
     if (LOADER == LOAD_V4) {
@@ -172,20 +172,22 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
       const long koff = (long)kdt * p.sT + (long)kdh * p.sH + (long)kdw * p.sW + kc;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const bool inb = kin && a_ok[i] && (unsigned)(a_t[i] + kdt) < (unsigned)p.T &&
                          (unsigned)(a_h[i] + kdh) < (unsigned)p.H && (unsigned)(a_w[i] + kdw) < (unsigned)p.W;
-        if (inb) {
-          v = *reinterpret_cast<const float4*>(p.x + a_off[i] + koff);
-          if (p.gate) {
-            const float4 g = *reinterpret_cast<const float4*>(p.gate + (long)a_n[i] * p.C + kc);
-            v.x = act_apply(v.x * g.x, MSPI_ACT_SWISH);
-            v.y = act_apply(v.y * g.y, MSPI_ACT_SWISH);
-            v.z = act_apply(v.z * g.z, MSPI_ACT_SWISH);
-            v.w = act_apply(v.w * g.w, MSPI_ACT_SWISH);
-          }
+        const float4 v = *reinterpret_cast<const float4*>(p.x + (inb ? a_off[i] + koff : 0));
+        ra[i] = inb ? v : make_float4(0.f, 0.f, 0.f, 0.f);   // swish(0 * g) = 0: masked rows stay zero under the gate
+      }
+      if (p.gate) {   // wave-uniform; all gate loads issued together, after the A loads
+        float4 g[AR];
+#pragma unroll
+        for (int i = 0; i < AR; ++i) g[i] = *reinterpret_cast<const float4*>(p.gate + (long)a_n[i] * p.C + (kin ? kc : 0));
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+          ra[i].x = act_apply(ra[i].x * g[i].x, MSPI_ACT_SWISH);
+          ra[i].y = act_apply(ra[i].y * g[i].y, MSPI_ACT_SWISH);
+          ra[i].z = act_apply(ra[i].z * g[i].z, MSPI_ACT_SWISH);
+          ra[i].w = act_apply(ra[i].w * g[i].w, MSPI_ACT_SWISH);
         }
-        ra[i] = v;
       }
       // advance the cursor by one BK chunk
       kc += BK;
@@ -218,7 +220,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
         for (int i = 0; i < AR; ++i) {
           const bool inb = kin && a_ok[i] && (unsigned)(a_t[i] + dt) < (unsigned)p.T &&
                            (unsigned)(a_h[i] + dh) < (unsigned)p.H && (unsigned)(a_w[i] + dw) < (unsigned)p.W;
-          va[i][e] = inb ? p.x[a_off[i] + koff] : 0.f;
+          const float t = p.x[inb ? a_off[i] + koff : 0];
+          va[i][e] = inb ? t : 0.f;
         }
       }
 #pragma unroll
@@ -237,16 +240,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
   const int Kloop = (int)p.ldw;  // ldw >= K by contract; [K, ldw) is zero in w and masked in A
   const int li = lane & 31, lh = lane >> 5;
 
-  load_tiles(0);
-  for (int k0 = 0; k0 < Kloop; k0 += BK) {
+  // registers -> LDS stage `st` (F16X3: split every fp32 activation into hi + lo halves on the way)
+  auto store_tiles = [&](int st) {
+    float* base = smem + st * STAGE;
     if (PREC == PREC_F32) {
+      float* As = base;
+      float* Bs = base + BM * LDK;
 #pragma unroll
       for (int i = 0; i < AR; ++i)
-        *reinterpret_cast<float4*>(&As[(rbase + 32 * i) * LDK + kv * 4]) = ra[i];
+        *reinterpret_cast<float4*>(&As[(rbase + RP * i) * LDK + kv * 4]) = ra[i];
 #pragma unroll
       for (int i = 0; i < BR; ++i)
-        *reinterpret_cast<float4*>(&Bs[(rbase + 32 * i) * LDK + kv * 4]) = rb[i];
+        if (rbase + RP * i < BN) *reinterpret_cast<float4*>(&Bs[(rbase + RP * i) * LDK + kv * 4]) = rb[i];
     } else {
+      _Float16* Ah = reinterpret_cast<_Float16*>(base);
+      _Float16* Al = Ah + BM * LDH;
+      _Float16* Bh = Al + BM * LDH;
+      _Float16* Bl = Bh + BN * LDH;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
         v4h hi, lo;
@@ -255,23 +265,29 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
         lo[1] = (_Float16)(ra[i].y - (float)hi[1]);
         lo[2] = (_Float16)(ra[i].z - (float)hi[2]);
         lo[3] = (_Float16)(ra[i].w - (float)hi[3]);
-        *reinterpret_cast<v4h*>(&Ah[(rbase + 32 * i) * LDH + kv * 4]) = hi;
-        *reinterpret_cast<v4h*>(&Al[(rbase + 32 * i) * LDH + kv * 4]) = lo;
+        *reinterpret_cast<v4h*>(&Ah[(rbase + RP * i) * LDH + kv * 4]) = hi;
+        *reinterpret_cast<v4h*>(&Al[(rbase + RP * i) * LDH + kv * 4]) = lo;
       }
 #pragma unroll
       for (int i = 0; i < HB; ++i) {
-        const int r = hrow + 64 * i;
+        const int r = hrow + HR * i;
         if (r < BN) {
           *reinterpret_cast<uint4*>(&Bh[r * LDH + hseg * 8]) = rbh[i];
           *reinterpret_cast<uint4*>(&Bl[r * LDH + hseg * 8]) = rbl[i];
         }
       }
     }
-    __syncthreads();
-    if (k0 + BK < Kloop) load_tiles(k0 + BK);  // next tile's loads fly under the MFMAs
+  };
+
+  // MFMAs of one half (kh = 0/1) of the K step held in LDS stage `st`
+  auto compute_half = [&](int st, int kh) {
+    const float* base = smem + st * STAGE;
     if (PREC == PREC_F32) {
+      const float* As = base;
+      const float* Bs = base + BM * LDK;
 #pragma unroll
-      for (int kk = 0; kk < BK / 8; ++kk) {
+      for (int kq = 0; kq < 2; ++kq) {
+        const int kk = kh * 2 + kq;
         float4 fa[TM], fb[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -291,31 +307,48 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
       }
     } else {
       // 32x32x16 f16: lane (i = lane&31, h = lane>>5) holds A[i][8h..8h+7] / B[8h..8h+7][j] of the 16-deep step
+      const _Float16* Ah = reinterpret_cast<const _Float16*>(base);
+      const _Float16* Al = Ah + BM * LDH;
+      const _Float16* Bh = Al + BM * LDH;
+      const _Float16* Bl = Bh + BN * LDH;
+      v8h ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-      for (int kk = 0; kk < BK / 16; ++kk) {
-        v8h ah[TM], al[TM], bh[TN], bl[TN];
+      for (int i = 0; i < TM; ++i) {
+        const int o = ((wm * TM + i) * 32 + li) * LDH + kh * 16 + lh * 8;
+        ah[i] = *reinterpret_cast<const v8h*>(&Ah[o]);
+        al[i] = *reinterpret_cast<const v8h*>(&Al[o]);
+      }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int o = ((wm * TM + i) * 32 + li) * LDH + kk * 16 + lh * 8;
-          ah[i] = *reinterpret_cast<const v8h*>(&Ah[o]);
-          al[i] = *reinterpret_cast<const v8h*>(&Al[o]);
-        }
+      for (int j = 0; j < TN; ++j) {
+        const int o = ((wn * TN + j) * 32 + li) * LDH + kh * 16 + lh * 8;
+        bh[j] = *reinterpret_cast<const v8h*>(&Bh[o]);
+        bl[j] = *reinterpret_cast<const v8h*>(&Bl[o]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int o = ((wn * TN + j) * 32 + li) * LDH + kk * 16 + lh * 8;
-          bh[j] = *reinterpret_cast<const v8h*>(&Bh[o]);
-          bl[j] = *reinterpret_cast<const v8h*>(&Bl[o]);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          }
-      }
     }
+  };
+
+  // Software pipeline: while stage `cur` is being multiplied, tile it+1 (already in registers) is split and
+  // written to the other stage and tile it+2 is requested from memory -- one barrier per K step, two tiles of
+  // global-load latency cover.
+  const int nk = (Kloop + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  if (nk > 1) load_tiles(BK);
+  __syncthreads();
+  for (int it = 0; it < nk; ++it) {
+    const int cur = it & 1;
+    compute_half(cur, 0);
+    if (it + 1 < nk) store_tiles(cur ^ 1);
+    if (it + 2 < nk) load_tiles((it + 2) * BK);
+    compute_half(cur, 1);
     __syncthreads();
   }
 
@@ -328,14 +361,22 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int rb0 = m0 + (wm * TM + i) * 32 + 4 * lh;
+      float rv[16];
+      if (p.res) {   // all 16 residual loads in flight together (one wait), not load-wait-store per element
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rb0 + (r & 3) + 8 * (r >> 2);
+          rv[r] = p.res[row < p.M ? (long)row * p.ldr + col : 0];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rb0 + (r & 3) + 8 * (r >> 2);
-        if (row < p.M) {
-          float v = (PREC == PREC_F32 ? acc[i][j][r] : acc[i][j][r] * p.out_scale) + bv;
-          if (p.res) v += p.res[(long)row * p.ldr + col];
-          p.y[(long)row * p.ldy + col] = act_apply(v, p.act);
-        }
+        const float v = (PREC == PREC_F32 ? acc[i][j][r] : acc[i][j][r] * p.out_scale) + bv + rv[r];
+        if (row < p.M) p.y[(long)row * p.ldy + col] = act_apply(v, p.act);
       }
     }
   }
@@ -343,7 +384,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs p) {
 
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(const ConvArgs& a, bool v4, int prec, hipStream_t s) {
-  const dim3 g(a.nblocks), b(256);
+  const dim3 g(a.nblocks), b(WM * WN * 64);
   if (prec == PREC_F32) {
     if (v4) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, LOAD_V4, PREC_F32>), g, b, 0, s, a);
     else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, LOAD_S, PREC_F32>), g, b, 0, s, a);
@@ -400,21 +441,22 @@ extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float*
   a.M = (int)Ml; a.K = (int)K; a.rows_per_sample = To * Ho * Wo;
   a.out_scale = d->prec == PREC_F16X3 ? 1.0f / d->w_scale : 1.0f;
 
-  // tile choice: least padded work, with a penalty for narrow tiles (more LDS traffic per
-  // MFMA) and for grids too small to fill 256 CUs.
+  // Tile choice: among the tiles whose grid fills the chip (>= 1.5 workgroups per CU) take the least padded
+  // work, weighted by a per-tile efficiency measured with tools/gemm_probe.py; small problems take 64x64.
   struct Cfg { int bm, bn; float eff; };
-  static const Cfg cfgs[4] = {{128, 128, 1.00f}, {128, 64, 1.08f}, {128, 32, 1.30f}, {64, 64, 1.25f}};
-  int best = 0;
+  static const Cfg cfgs[6] = {{128, 128, 1.00f}, {128, 64, 1.12f}, {128, 32, 1.40f}, {64, 64, 1.25f},
+                              {128, 128, 1.00f}, {256, 128, 1.10f}};
+  static const int force = getenv("MSPI_CONV_TILE") ? atoi(getenv("MSPI_CONV_TILE")) : -1;
+  int best = 3;
   double best_cost = 1e300;
   for (int i = 0; i < 4; ++i) {
     const long tm = (Ml + cfgs[i].bm - 1) / cfgs[i].bm, tn = (d->Cout + cfgs[i].bn - 1) / cfgs[i].bn;
-    const long blocks = tm * tn;
-    // time ~ (#waves of resident workgroups) x (work per workgroup)
-    double waves = (double)blocks / 512.0;  // 256 CUs x 2 resident workgroups
-    if (waves < 1.0) waves = 1.0;
-    const double cost = waves * cfgs[i].bm * cfgs[i].bn * cfgs[i].eff;
+    if (tm * tn < 384 && i != 3) continue;
+    const double cost = (double)(tm * cfgs[i].bm) * (double)(tn * cfgs[i].bn) * cfgs[i].eff;
     if (cost < best_cost) { best_cost = cost; best = i; }
   }
+  if (best == 0 && !getenv("MSPI_CONV_4WAVE")) best = 4;   // 128x128 runs best with 8 waves (32x64 per wave, 4 waves/SIMD)
+  if (force >= 0 && force < 6) best = force;
   const int BMs = cfgs[best].bm, BNs = cfgs[best].bn;
   a.tiles_n = (d->Cout + BNs - 1) / BNs;
   const long nb = ((Ml + BMs - 1) / BMs) * a.tiles_n;
@@ -426,6 +468,8 @@ extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float*
     case 0: launch_cfg<128, 128, 2, 2>(a, v4, d->prec, s); break;
     case 1: launch_cfg<128, 64, 2, 2>(a, v4, d->prec, s); break;
     case 2: launch_cfg<128, 32, 4, 1>(a, v4, d->prec, s); break;
+    case 4: launch_cfg<128, 128, 4, 2>(a, v4, d->prec, s); break;   // 8 waves, 32x64 per wave
+    case 5: launch_cfg<256, 128, 4, 2>(a, v4, d->prec, s); break;   // 8 waves, 64x64 per wave
     default: launch_cfg<64, 64, 2, 2>(a, v4, d->prec, s); break;
   }
   return check_launch("mspi_conv_fwd");
