@@ -141,13 +141,15 @@ int mspi_layernorm_fwd(const float* x, int64_t ldx, int64_t sNx, float* y, int64
 
 /* ------------------------------------------------------------------------------------
  * Fused multi-head attention (flash style, MFMA, online softmax, fp32):
- *   o[b,h,i,:] = softmax_j( scale * q[b,h,i,:] . k[b,h,j,:] ) v[b,h,j,:]
- * q/k/v/o are addressed as base + b*sB + h*sH + token*sT + d (d contiguous).
- * Replaces model/model_utils.py:102-106 (SyncBlock attention).
- * head_dim must be a multiple of 32 and <= 128.
+ *   o[b,h,i,:] = softmax_j( scale * q[b,h,i,:] . k[b,h,j,:] + biasT[h,j,i] + maskT[b % nmask,j,i] ) v[b,h,j,:] (+ res)
+ * q/k/v/o (and res, with o's strides) are addressed as base + b*sB + h*sH + token*sT + d (d contiguous).
+ * D = head dim of q/k, Dv = head dim of v/o; (D,Dv) in {(32,32),(64,64),(96,96),(128,128),(128,96),(160,96)}.
+ * biasT / maskT (optional) are stored key-major ([.][Nk][Nq]).
+ * Replaces model/model_utils.py:102-106 (SyncBlock), backbones/MViT.py:1261-1301 (pooled attention, residual
+ * pooling as `res`), backbones/video_swin_transformer.py:169-187 (window attention, bias table + shift mask).
  * ------------------------------------------------------------------------------------ */
 typedef struct MspiAttnDesc {
-  int32_t B, Hh, Nq, Nk, D;
+  int32_t B, Hh, Nq, Nk, D, Dv, nmask;
   int64_t q_sB, q_sH, q_sT;
   int64_t k_sB, k_sH, k_sT;
   int64_t v_sB, v_sH, v_sT;
@@ -155,8 +157,24 @@ typedef struct MspiAttnDesc {
   float scale;
 } MspiAttnDesc;
 
-int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float* k, const float* v, float* o,
-                  mspi_stream_t stream);
+int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float* k, const float* v, const float* res,
+                  const float* biasT, const float* maskT, float* o, mspi_stream_t stream);
+
+/* MViTv2 decomposed relative positions folded into the attention contraction (backbones/MViT.py:905-997):
+ *   qa[b,h,i,:] = [ scale*q_i | q_i.Rh[hq(i),0..kH) | q_i.Rw[wq(i),0..kW) | q_i.Rt[tq(i),0..kT) | 0 ]   (DA columns)
+ *   ka[b,h,j,:] = [ k_j | onehot_kH(hk(j)) | onehot_kW(wk(j)) | onehot_kT(tk(j)) | 0 ]
+ * so that qa.ka^T = scale*q.k + rel_h + rel_w + rel_t exactly; feed qa/ka to mspi_attn_fwd with D = DA, scale 1.
+ * q rows are [B*Nq][ldq] with head h at column h*Dh (likewise k); Rh/Rw/Rt are the gathered tables
+ * [qH][kH][Dh], [qW][kW][Dh], [qT][kT][Dh]. */
+typedef struct MspiMvitAugDesc {
+  int32_t B, heads, Dh, DA;
+  int32_t qT, qH, qW, kT, kH, kW;
+  int64_t ldq, ldk;
+  float scale;
+} MspiMvitAugDesc;
+
+int mspi_mvit_qk_augment(const MspiMvitAugDesc* d, const float* q, const float* k, const float* Rh, const float* Rw,
+                         const float* Rt, float* qa, float* ka, mspi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Max pooling, channels-last, -inf padding.

@@ -23,18 +23,24 @@ struct AttnArgs {
   const float* q;
   const float* k;
   const float* v;
+  const float* res;    // optional, added to the output (o strides)
+  const float* biasT;  // optional [Hh][Nk][Nq]: transposed additive bias (key-major so a lane row is coalesced)
+  const float* maskT;  // optional [nmask][Nk][Nq]: additive mask, sequence b uses slice b % nmask
   float* o;
-  int B, Hh, Nq, Nk;
+  int B, Hh, Nq, Nk, nmask;
   long q_sB, q_sH, q_sT, k_sB, k_sH, k_sT, v_sB, v_sH, v_sT, o_sB, o_sH, o_sT;
   float scale;
 };
 
-template <int D>
+// D = head dim of Q/K (the contraction of S), DV = head dim of V / O.  They differ for MViT, whose decomposed
+// relative-position terms ride along as extra Q/K columns (mvit_aug_kernel below).
+template <int D, int DV>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   constexpr int LDD = D + 4;
-  constexpr int NC = D / 8;   // float4 chunks of one lane half
-  constexpr int NT = D / 32;  // 32-wide output tiles along d
-  __shared__ __attribute__((aligned(16))) float smem[2 * 32 * LDD];
+  constexpr int LDV = DV + 4;
+  constexpr int NC = D / 8;    // float4 chunks of one lane half
+  constexpr int NT = DV / 32;  // 32-wide output tiles along d
+  __shared__ __attribute__((aligned(16))) float smem[32 * LDD + 32 * LDV];
   float* Ks = smem;
   float* Vs = smem + 32 * LDD;
 
@@ -69,13 +75,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     __syncthreads();  // previous tile fully consumed
     for (int idx = tid; idx < 32 * (D / 4); idx += 256) {
       const int row = idx / (D / 4), c4 = idx - row * (D / 4);
-      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-      if (k0 + row < p.Nk) {
-        kv = *reinterpret_cast<const float4*>(kb + (long)(k0 + row) * p.k_sT + c4 * 4);
-        vv = *reinterpret_cast<const float4*>(vb + (long)(k0 + row) * p.v_sT + c4 * 4);
-      }
-      *reinterpret_cast<float4*>(&Ks[row * LDD + c4 * 4]) = kv;
-      *reinterpret_cast<float4*>(&Vs[row * LDD + c4 * 4]) = vv;
+      const bool ok = k0 + row < p.Nk;
+      const float4 kv = *reinterpret_cast<const float4*>(kb + (ok ? (long)(k0 + row) * p.k_sT + c4 * 4 : 0));
+      *reinterpret_cast<float4*>(&Ks[row * LDD + c4 * 4]) = ok ? kv : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int idx = tid; idx < 32 * (DV / 4); idx += 256) {
+      const int row = idx / (DV / 4), c4 = idx - row * (DV / 4);
+      const bool ok = k0 + row < p.Nk;
+      const float4 vv = *reinterpret_cast<const float4*>(vb + (ok ? (long)(k0 + row) * p.v_sT + c4 * 4 : 0));
+      *reinterpret_cast<float4*>(&Vs[row * LDV + c4 * 4]) = ok ? vv : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
 
@@ -94,6 +102,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 
     // online softmax over the 32 keys of this tile (16 in my registers, 16 in lane^32's)
     float mt = -INFINITY;
+    if (p.biasT || p.maskT) {   // wave-uniform: Swin's learned bias table / shifted-window mask
+      const float* bt = p.biasT ? p.biasT + (long)h * p.Nk * p.Nq : nullptr;
+      const float* mk = p.maskT ? p.maskT + (long)(b % p.nmask) * p.Nk * p.Nq : nullptr;
+      float add[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const long o = (qok && key < p.Nk) ? (long)key * p.Nq + q : 0;
+        add[r] = (bt ? bt[o] : 0.f) + (mk ? mk[o] : 0.f);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] += add[r];
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -123,7 +144,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
       const int krow = (r & 3) + 8 * (r >> 2) + 4 * lh;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const float vf = Vs[krow * LDD + t * 32 + li];
+        const float vf = Vs[krow * LDV + t * 32 + li];
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], acc[t], 0, 0, 0);
       }
     }
@@ -131,16 +152,89 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 
   if (qok) {
     const float inv = 1.f / l_run;
-    float* op = p.o + (long)b * p.o_sB + (long)h * p.o_sH + (long)q * p.o_sT;
+    const long oo = (long)b * p.o_sB + (long)h * p.o_sH + (long)q * p.o_sT;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         // registers 4g..4g+3 are 4 consecutive d: d = t*32 + 8g + 4*lh + (0..3)
-        const float4 o4 = make_float4(acc[t][4 * g] * inv, acc[t][4 * g + 1] * inv, acc[t][4 * g + 2] * inv,
-                                      acc[t][4 * g + 3] * inv);
-        *reinterpret_cast<float4*>(op + t * 32 + 8 * g + 4 * lh) = o4;
+        float4 o4 = make_float4(acc[t][4 * g] * inv, acc[t][4 * g + 1] * inv, acc[t][4 * g + 2] * inv,
+                                acc[t][4 * g + 3] * inv);
+        const int dd = t * 32 + 8 * g + 4 * lh;
+        if (p.res) {
+          const float4 rr = *reinterpret_cast<const float4*>(p.res + oo + dd);
+          o4.x += rr.x; o4.y += rr.y; o4.z += rr.z; o4.w += rr.w;
+        }
+        *reinterpret_cast<float4*>(p.o + oo + dd) = o4;
       }
+  }
+}
+
+// ------------------------------------------------------------------ MViTv2 decomposed relative positions
+// attn = (q*scale) k^T + q.Rh[hq,hk] + q.Rw[wq,wk] + q.Rt[tq,tk]   (backbones/MViT.py:905-997,1261-1290).
+// The three rank-structured terms are folded into the contraction itself: Q gets J = kH+kW+kT extra columns
+// holding q.R*(own position, j) and K gets the matching one-hot columns, so one fused attention pass over
+// D + J columns reproduces the sum exactly (a 1.0 x value product is exact) -- no bias matrix exists anywhere.
+struct AugArgs {
+  const float* q;   // pooled + normed q rows [B*Nq][ldq], head h at column h*Dh
+  const float* k;   // pooled + normed k rows [B*Nk][ldk]
+  const float* Rh;  // [qH][kH][Dh] gathered tables
+  const float* Rw;  // [qW][kW][Dh]
+  const float* Rt;  // [qT][kT][Dh]
+  float* qa;        // [B][heads][Nq][DA]
+  float* ka;        // [B][heads][Nk][DA]
+  int B, heads, Dh, DA;
+  int qT, qH, qW, kT, kH, kW;
+  long ldq, ldk;
+  float scale;
+};
+
+__global__ __launch_bounds__(256) void mvit_aug_kernel(const AugArgs p) {
+  const int Nq = p.qT * p.qH * p.qW, Nk = p.kT * p.kH * p.kW;
+  const int J = p.kH + p.kW + p.kT;
+  const long qrows = (long)p.B * p.heads * Nq, krows = (long)p.B * p.heads * Nk;
+  const long total = (qrows + krows) * p.DA;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int col = (int)(idx % p.DA);
+    long row = idx / p.DA;
+    if (row < qrows) {
+      const int tok = (int)(row % Nq);
+      const long bh = row / Nq;
+      const int hd = (int)(bh % p.heads);
+      const long b = bh / p.heads;
+      const float* qr = p.q + (b * Nq + tok) * p.ldq + (long)hd * p.Dh;
+      float v = 0.f;
+      if (col < p.Dh) {
+        v = qr[col] * p.scale;
+      } else if (col < p.Dh + J) {
+        const int j = col - p.Dh;
+        const int wq = tok % p.qW, hq = (tok / p.qW) % p.qH, tq = tok / (p.qW * p.qH);
+        const float* tab = j < p.kH ? p.Rh + ((long)hq * p.kH + j) * p.Dh
+                         : j < p.kH + p.kW ? p.Rw + ((long)wq * p.kW + (j - p.kH)) * p.Dh
+                                           : p.Rt + ((long)tq * p.kT + (j - p.kH - p.kW)) * p.Dh;
+        for (int c = 0; c < p.Dh; c += 4) {
+          const float4 a = *reinterpret_cast<const float4*>(qr + c);
+          const float4 t = *reinterpret_cast<const float4*>(tab + c);
+          v = fmaf(a.x, t.x, v); v = fmaf(a.y, t.y, v); v = fmaf(a.z, t.z, v); v = fmaf(a.w, t.w, v);
+        }
+      }
+      p.qa[row * p.DA + col] = v;
+    } else {
+      row -= qrows;
+      const int tok = (int)(row % Nk);
+      const long bh = row / Nk;
+      const int hd = (int)(bh % p.heads);
+      const long b = bh / p.heads;
+      float v = 0.f;
+      if (col < p.Dh) {
+        v = p.k[(b * Nk + tok) * p.ldk + (long)hd * p.Dh + col];
+      } else if (col < p.Dh + J) {
+        const int j = col - p.Dh;
+        const int wk = tok % p.kW, hk = (tok / p.kW) % p.kH, tk = tok / (p.kW * p.kH);
+        v = (j == hk || j == p.kH + wk || j == p.kH + p.kW + tk) ? 1.f : 0.f;
+      }
+      p.ka[row * p.DA + col] = v;
+    }
   }
 }
 
@@ -148,18 +242,39 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 
 using namespace mspi;
 
-extern "C" int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float* k, const float* v, float* o,
-                             mspi_stream_t stream) {
+extern "C" int mspi_mvit_qk_augment(const MspiMvitAugDesc* d, const float* q, const float* k, const float* Rh,
+                                    const float* Rw, const float* Rt, float* qa, float* ka, mspi_stream_t stream) {
+  MSPI_REQUIRE(d && q && k && Rh && Rw && Rt && qa && ka, "mspi_mvit_qk_augment: null argument");
+  MSPI_REQUIRE(d->B > 0 && d->heads > 0 && d->Dh > 0 && (d->Dh & 3) == 0 && d->DA >= d->Dh + d->kH + d->kW + d->kT,
+               "mspi_mvit_qk_augment: DA=%d too small for Dh=%d + %d relative-position columns", d->DA, d->Dh,
+               d->kH + d->kW + d->kT);
+  MSPI_REQUIRE((d->ldq & 3) == 0 && (d->ldk & 3) == 0 && aligned16(q) && aligned16(k) && aligned16(Rh) && aligned16(Rw) &&
+                   aligned16(Rt), "mspi_mvit_qk_augment: 16-B alignment");
+  AugArgs a;
+  a.q = q; a.k = k; a.Rh = Rh; a.Rw = Rw; a.Rt = Rt; a.qa = qa; a.ka = ka;
+  a.B = d->B; a.heads = d->heads; a.Dh = d->Dh; a.DA = d->DA;
+  a.qT = d->qT; a.qH = d->qH; a.qW = d->qW; a.kT = d->kT; a.kH = d->kH; a.kW = d->kW;
+  a.ldq = d->ldq; a.ldk = d->ldk; a.scale = d->scale;
+  const long total = ((long)d->B * d->heads * (d->qT * d->qH * d->qW + d->kT * d->kH * d->kW)) * d->DA;
+  long g = (total + 255) / 256;
+  if (g > 256L * 32) g = 256L * 32;
+  hipLaunchKernelGGL(mvit_aug_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("mspi_mvit_qk_augment");
+}
+
+extern "C" int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float* k, const float* v, const float* res,
+                             const float* biasT, const float* maskT, float* o, mspi_stream_t stream) {
   MSPI_REQUIRE(d && q && k && v && o, "mspi_attn_fwd: null argument");
   MSPI_REQUIRE(d->B > 0 && d->Hh > 0 && d->Nq > 0 && d->Nk > 0, "mspi_attn_fwd: empty extent");
-  MSPI_REQUIRE(d->D == 32 || d->D == 64 || d->D == 96 || d->D == 128, "mspi_attn_fwd: head_dim %d not in {32,64,96,128}", d->D);
   const int64_t st[12] = {d->q_sB, d->q_sH, d->q_sT, d->k_sB, d->k_sH, d->k_sT, d->v_sB, d->v_sH, d->v_sT, d->o_sB, d->o_sH, d->o_sT};
   for (int i = 0; i < 12; ++i) MSPI_REQUIRE((st[i] & 3) == 0, "mspi_attn_fwd: strides must be multiples of 4 floats");
-  MSPI_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o), "mspi_attn_fwd: pointers must be 16-B aligned");
+  MSPI_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && (!res || aligned16(res)),
+               "mspi_attn_fwd: pointers must be 16-B aligned");
   MSPI_REQUIRE((long)d->B * d->Hh < 65536, "mspi_attn_fwd: B*H too large");
+  MSPI_REQUIRE(!maskT || d->nmask > 0, "mspi_attn_fwd: mask needs nmask > 0");
   AttnArgs a;
-  a.q = q; a.k = k; a.v = v; a.o = o;
-  a.B = d->B; a.Hh = d->Hh; a.Nq = d->Nq; a.Nk = d->Nk;
+  a.q = q; a.k = k; a.v = v; a.res = res; a.biasT = biasT; a.maskT = maskT; a.o = o;
+  a.B = d->B; a.Hh = d->Hh; a.Nq = d->Nq; a.Nk = d->Nk; a.nmask = d->nmask > 0 ? d->nmask : 1;
   a.q_sB = d->q_sB; a.q_sH = d->q_sH; a.q_sT = d->q_sT;
   a.k_sB = d->k_sB; a.k_sH = d->k_sH; a.k_sT = d->k_sT;
   a.v_sB = d->v_sB; a.v_sH = d->v_sH; a.v_sT = d->v_sT;
@@ -167,11 +282,17 @@ extern "C" int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float*
   a.scale = d->scale;
   dim3 grid((unsigned)((d->Nq + 127) / 128), (unsigned)(d->B * d->Hh));
   hipStream_t s = (hipStream_t)stream;
-  switch (d->D) {
-    case 32: hipLaunchKernelGGL((attn_kernel<32>), grid, dim3(256), 0, s, a); break;
-    case 64: hipLaunchKernelGGL((attn_kernel<64>), grid, dim3(256), 0, s, a); break;
-    case 96: hipLaunchKernelGGL((attn_kernel<96>), grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL((attn_kernel<128>), grid, dim3(256), 0, s, a); break;
+  const int key = d->D * 1000 + d->Dv;
+  switch (key) {
+    case 32032: hipLaunchKernelGGL((attn_kernel<32, 32>), grid, dim3(256), 0, s, a); break;
+    case 64064: hipLaunchKernelGGL((attn_kernel<64, 64>), grid, dim3(256), 0, s, a); break;
+    case 96096: hipLaunchKernelGGL((attn_kernel<96, 96>), grid, dim3(256), 0, s, a); break;
+    case 128128: hipLaunchKernelGGL((attn_kernel<128, 128>), grid, dim3(256), 0, s, a); break;
+    case 128096: hipLaunchKernelGGL((attn_kernel<128, 96>), grid, dim3(256), 0, s, a); break;
+    case 160096: hipLaunchKernelGGL((attn_kernel<160, 96>), grid, dim3(256), 0, s, a); break;
+    default:
+      set_error("mspi_attn_fwd: (D=%d, Dv=%d) not in {(32,32),(64,64),(96,96),(128,128),(128,96),(160,96)}", d->D, d->Dv);
+      return MSPI_EINVAL;
   }
   return check_launch("mspi_attn_fwd");
 }

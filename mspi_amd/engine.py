@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH, PREC_F16X3, PREC_F32, AttnDesc, ConvDesc,
-                   DwConvDesc, MspiError, check)
+                   DwConvDesc, MspiError, MvitAugDesc, check)
 
 # GEMM arithmetic for every dense conv / Linear: "f16x3" (default; fp32-accurate split product on the f16 matrix
 # pipe, see include/mspi_hip.h) or "f32" (v_mfma_f32_32x32x2_f32).  Read when weights are packed.
@@ -388,24 +388,66 @@ def layernorm(x, gamma, beta, eps, out=None, act=ACT_NONE, table=None):
     return out
 
 
-def attention(qkv, B, Ntok, heads, hd, scale, out=None):
+def attention(qkv, B, Ntok, heads, hd, scale, out=None, biasT=None, maskT=None):
     """qkv: CL with rows (b, token) and 3*heads*hd columns laid out [3][heads][hd]
-    (what `qkv.reshape(B,N,3,h,hd)` means, model/model_utils.py:100)."""
+    (what `qkv.reshape(B,N,3,h,hd)` means, model/model_utils.py:100).  B sequences of Ntok tokens.
+    biasT [heads][Ntok][Ntok] / maskT [nmask][Ntok][Ntok]: key-major additive terms (Swin)."""
     lib = _lib.load()
     Cc = heads * hd
-    assert qkv.C == 3 * Cc and qkv.M == B * Ntok
+    assert qkv.C == 3 * Cc and qkv.M == B * Ntok and qkv.dense
     if out is None:
         out = alloc(qkv.N, qkv.T, qkv.H, qkv.W, Cc, qkv.buf.device)
     d = AttnDesc()
-    d.B, d.Hh, d.Nq, d.Nk, d.D = B, heads, Ntok, Ntok, hd
+    d.B, d.Hh, d.Nq, d.Nk, d.D, d.Dv = B, heads, Ntok, Ntok, hd, hd
+    d.nmask = 0 if maskT is None else maskT.shape[0]
     d.q_sB = d.k_sB = d.v_sB = Ntok * qkv.ld
     d.q_sH = d.k_sH = d.v_sH = hd
     d.q_sT = d.k_sT = d.v_sT = qkv.ld
     d.o_sB, d.o_sH, d.o_sT = Ntok * out.ld, hd, out.ld
     d.scale = float(scale)
     base = qkv.ptr
-    with _Timed("attention", 4.0 * B * heads * Ntok * Ntok * hd, 16.0 * B * Ntok * Cc):
-        check(lib.mspi_attn_fwd(C.byref(d), base, base + 4 * Cc, base + 8 * Cc, out.ptr, _stream()), "mspi_attn_fwd")
+    with _Timed("attention", 4.0 * B * heads * Ntok * Ntok * hd, 16.0 * B * Ntok * Cc, "B=%d h=%d N=%d d=%d" % (B, heads, Ntok, hd)):
+        check(lib.mspi_attn_fwd(C.byref(d), base, base + 4 * Cc, base + 8 * Cc, None,
+                                biasT.data_ptr() if biasT is not None else None,
+                                maskT.data_ptr() if maskT is not None else None, out.ptr, _stream()), "mspi_attn_fwd")
+    return out
+
+
+def mvit_attention(q, k, v, B, heads, hd, scale, q_thw, k_thw, Rh, Rw, Rt, out=None):
+    """MViTv2 pooled attention with decomposed relative positions and residual pooling (backbones/MViT.py:1261-1301).
+    q: CL rows (b, tq,hq,wq) x heads*hd (pooled + normed); k, v likewise over the pooled key grid.
+    Returns CL rows (b, q token) x heads*hd = softmax(...) v + q."""
+    lib = _lib.load()
+    Nq, Nk = q_thw[0] * q_thw[1] * q_thw[2], k_thw[0] * k_thw[1] * k_thw[2]
+    J = k_thw[0] + k_thw[1] + k_thw[2]
+    DA = 128 if hd + J <= 128 else 160
+    if hd != 96 or hd + J > DA:
+        raise MspiError("mvit_attention: head_dim %d with %d relative-position columns is not instantiated" % (hd, J))
+    dev = q.buf.device
+    qa = torch.empty(B * heads * Nq * DA, dtype=torch.float32, device=dev)
+    ka = torch.empty(B * heads * Nk * DA, dtype=torch.float32, device=dev)
+    a = MvitAugDesc()
+    a.B, a.heads, a.Dh, a.DA = B, heads, hd, DA
+    a.qT, a.qH, a.qW = q_thw
+    a.kT, a.kH, a.kW = k_thw
+    a.ldq, a.ldk, a.scale = q.ld, k.ld, float(scale)
+    with _Timed("mvit_qk_augment", 2.0 * B * heads * Nq * J * hd, 4.0 * B * heads * (Nq + Nk) * (hd + DA)):
+        check(lib.mspi_mvit_qk_augment(C.byref(a), q.ptr, k.ptr, Rh.data_ptr(), Rw.data_ptr(), Rt.data_ptr(),
+                                       qa.data_ptr(), ka.data_ptr(), _stream()), "mspi_mvit_qk_augment")
+    if out is None:
+        out = alloc(q.N, q.T, q.H, q.W, heads * hd, dev)
+    d = AttnDesc()
+    d.B, d.Hh, d.Nq, d.Nk, d.D, d.Dv, d.nmask = B, heads, Nq, Nk, DA, hd, 0
+    d.q_sB, d.q_sH, d.q_sT = heads * Nq * DA, Nq * DA, DA
+    d.k_sB, d.k_sH, d.k_sT = heads * Nk * DA, Nk * DA, DA
+    d.v_sB, d.v_sH, d.v_sT = Nk * v.ld, hd, v.ld
+    d.o_sB, d.o_sH, d.o_sT = Nq * out.ld, hd, out.ld
+    d.scale = 1.0
+    assert q.ld == out.ld and q.dense and out.dense   # residual pooling reads q with o's strides
+    with _Timed("attention", 2.0 * B * heads * Nq * Nk * (DA + hd), 4.0 * B * heads * (Nq * (DA + 2 * hd) + Nk * (DA + hd)),
+                "B=%d h=%d Nq=%d Nk=%d d=%d+%d" % (B, heads, Nq, Nk, DA, hd)):
+        check(lib.mspi_attn_fwd(C.byref(d), qa.data_ptr(), ka.data_ptr(), v.ptr, q.ptr, None, None, out.ptr, _stream()),
+              "mspi_attn_fwd")
     return out
 
 

@@ -148,6 +148,28 @@ def case_slowfast_backbone(size=64, seed=0):
     _save("slowfast_backbone_%d" % size, seed=seed, size=size, batch=2, sd_crc=T.sd_checksum(sd), **_feat_fixture(feats))
 
 
+def case_mvit_backbone(size=224, seed=0):
+    """MViT's feature taps hard-code h in [56,28,14,7] (backbones/MViT.py:2063,2073): 224x224 only."""
+    from mspi_amd.backbones.MViT import MViT
+    from mspi_amd.config import cfg as pcfg
+    prod = T.seeded(lambda: MViT(pcfg.MODEL.MVIT2.PATH_CFG), seed)
+    sd = prod.state_dict()
+    rcfg = rh.with_config("mvitv2s")
+    from backbones.MViT import MViT as RefMViT
+    ref = RefMViT(path_to_configs=rcfg.MODEL.MVIT2.PATH_CFG).eval()
+    ref.load_state_dict(sd, strict=True)
+    clips, _ = T.synth_inputs(1, 16, size, size, seed=seed)
+    with torch.no_grad():
+        feats = ref([clips])
+        ora = R.mvit_forward(sd, clips, R.MVIT_S_ARCH)
+    _check_restatement("mvit backbone", feats, ora, 5e-5)
+    _save("mvit_backbone_%d" % size, seed=seed, size=size, batch=1, sd_crc=T.sd_checksum(sd), **_feat_fixture(feats))
+
+
+def case_av_mvit_224():
+    _model_case("mvitv2s", "AudioVisualSaliencyModel", 224, 1, 111, 0, "av_mvit_224")
+
+
 def case_av_slowfast_64():
     _model_case("slowfast4x16", "AudioVisualSaliencyModel", 64, 2, 111, 0, "av_slowfast_64")
 

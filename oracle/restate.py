@@ -141,6 +141,80 @@ def slowfast_forward(sd, x, prefix="", alpha=4):
     return feats
 
 
+# ------------------------------------------------------------------------------- MViTv2
+def _mvit_pool(sd, p, x, thw, heads, stride, which):
+    """attention_pool with a conv (backbones/MViT.py:170-204): per-head depthwise 3x3x3 conv + LayerNorm(1e-6)."""
+    B, N, Cc = x.shape
+    hd = Cc // heads
+    t = x.reshape(B, N, heads, hd).permute(0, 2, 1, 3)                       # [B, heads, N, hd]
+    t = t.reshape(B * heads, thw[0], thw[1], thw[2], hd).permute(0, 4, 1, 2, 3)
+    w = sd["%s.pool_%s.weight" % (p, which)]
+    t = F.conv3d(t, w, None, stride, [k // 2 for k in w.shape[2:]], 1, hd)
+    new_thw = list(t.shape[2:])
+    t = t.reshape(B, heads, hd, -1).transpose(2, 3)
+    return _ln(sd, "%s.norm_%s" % (p, which), t, 1e-6), new_thw
+
+
+def _rel_tab(rel_pos, qs, ks):
+    d = int(2 * max(qs, ks) - 1)
+    if rel_pos.shape[0] != d:   # get_rel_pos, backbones/MViT.py:207-220
+        rel_pos = F.interpolate(rel_pos.reshape(1, rel_pos.shape[0], -1).permute(0, 2, 1), size=d, mode="linear")
+        rel_pos = rel_pos.reshape(-1, d).permute(1, 0)
+    qr, kr = max(ks / qs, 1.0), max(qs / ks, 1.0)
+    dist = torch.arange(qs)[:, None] * qr - torch.arange(ks)[None, :] * kr + (ks - 1) * kr
+    return rel_pos[dist.long()]
+
+
+def mvit_block(sd, p, x, thw, heads, stride_q, stride_kv):
+    """MultiScaleBlock + MultiScaleAttention (backbones/MViT.py:1016-1434), MViTv2-S settings: conv pooling,
+    decomposed spatial + temporal relative positions, residual pooling, channel expansion inside attention."""
+    B, N, dim = x.shape
+    xn = _ln(sd, p + ".norm1", x, 1e-6)
+    att = sd[p + ".attn.proj.weight"].shape[0]
+    hd = att // heads
+    qkv = _lin(sd, p + ".attn.qkv", xn).reshape(B, N, 3, att)
+    q, q_thw = _mvit_pool(sd, p + ".attn", qkv[:, :, 0], thw, heads, stride_q, "q")
+    k, k_thw = _mvit_pool(sd, p + ".attn", qkv[:, :, 1], thw, heads, stride_kv, "k")
+    v, _ = _mvit_pool(sd, p + ".attn", qkv[:, :, 2], thw, heads, stride_kv, "v")
+    attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    rq = q.reshape(B, heads, q_thw[0], q_thw[1], q_thw[2], hd)
+    Rh = _rel_tab(sd[p + ".attn.rel_pos_h"], q_thw[1], k_thw[1])
+    Rw = _rel_tab(sd[p + ".attn.rel_pos_w"], q_thw[2], k_thw[2])
+    Rt = _rel_tab(sd[p + ".attn.rel_pos_t"], q_thw[0], k_thw[0])
+    rel_h = torch.einsum("bythwc,hkc->bythwk", rq, Rh)
+    rel_w = torch.einsum("bythwc,wkc->bythwk", rq, Rw)
+    rel_t = torch.einsum("bythwc,tkc->bythwk", rq, Rt)
+    attn = (attn.view(B, heads, q_thw[0], q_thw[1], q_thw[2], k_thw[0], k_thw[1], k_thw[2])
+            + rel_h[:, :, :, :, :, None, :, None] + rel_w[:, :, :, :, :, None, None, :]
+            + rel_t[:, :, :, :, :, :, None, None]).view(B, heads, q.shape[2], k.shape[2])
+    o = attn.softmax(-1) @ v + q                                           # residual pooling
+    o = _lin(sd, p + ".attn.proj", o.transpose(1, 2).reshape(B, -1, att))
+    skip = _lin(sd, p + ".proj", xn) if p + ".proj.weight" in sd else x   # DIM_MUL_IN_ATT (:1414-1415)
+    if max(stride_q) > 1:
+        ks = [s + 1 if s > 1 else s for s in stride_q]
+        t = skip.reshape(B, thw[0], thw[1], thw[2], -1).permute(0, 4, 1, 2, 3)
+        t = F.max_pool3d(t, ks, stride_q, [kk // 2 for kk in ks])
+        skip = t.flatten(2).transpose(1, 2)
+    x = skip + o
+    x = x + _lin(sd, p + ".mlp.fc2", F.gelu(_lin(sd, p + ".mlp.fc1", _ln(sd, p + ".norm2", x, 1e-6))))
+    return x, q_thw
+
+
+def mvit_forward(sd, clips, arch, prefix=""):
+    """backbones/MViT.py:2016-2076.  arch: per block (heads, stride_q, stride_kv); taps after blocks 0,2,13,15."""
+    p = prefix
+    w = sd[p + "patch_embed.proj.weight"]
+    x = F.conv3d(clips, w, sd[p + "patch_embed.proj.bias"], arch["patch_stride"], arch["patch_padding"])
+    thw = list(x.shape[2:])
+    x = x.flatten(2).transpose(1, 2)
+    feats = []
+    for i, (heads, sq, skv) in enumerate(arch["blocks"]):
+        x, thw = mvit_block(sd, "%sblocks.%d" % (p, i), x, thw, heads, sq, skv)
+        if i in (0, 2, 13, 15):
+            feats.append(x.transpose(1, 2).reshape(x.shape[0], -1, thw[0], thw[1], thw[2]))
+    return feats
+
+
 # ------------------------------------------------------------------------------- audio ResNet-18
 def resnet18_forward(sd, x, prefix=""):
     """backbones/resnet.py:57-143 (1-channel stem, BasicBlock x [2,2,2,2], returns layer4 map)."""
@@ -348,6 +422,12 @@ def pack_clips(name, clips):
 BACKBONES = {}  # name -> fn(sd, packed_clips, prefix) -> [v1..v4]; filled below and by restate_tx.py
 BACKBONES["x3dl"] = lambda sd, x, prefix: x3d_forward(sd, x[0], prefix)
 BACKBONES["slowfast4x16"] = lambda sd, x, prefix: slowfast_forward(sd, x, prefix)
+MVIT_S_ARCH = {   # configs/MVITv2_S_16x4.yaml resolved the way MViT.__init__ does (backbones/MViT.py:1779-1826)
+    "patch_stride": (2, 4, 4), "patch_padding": (1, 3, 3),
+    "blocks": [(1, (1, 1, 1), (1, 8, 8)), (2, (1, 2, 2), (1, 4, 4)), (2, (1, 1, 1), (1, 4, 4)), (4, (1, 2, 2), (1, 2, 2))]
+              + [(4, (1, 1, 1), (1, 2, 2))] * 10 + [(8, (1, 2, 2), (1, 1, 1)), (8, (1, 1, 1), (1, 1, 1))],
+}
+BACKBONES["mvitv2s"] = lambda sd, x, prefix: mvit_forward(sd, x[0], MVIT_S_ARCH, prefix)
 
 
 def audio_visual_forward(sd, clips, audios, name, lateral_bool, lateral_stride, num_frames=16):

@@ -45,9 +45,9 @@ def test_descriptor_validation_without_gpu():
     assert b"does not match" in lib.mspi_last_error()
     a = _lib.AttnDesc()
     a.B = a.Hh = a.Nq = a.Nk = 1
-    a.D = 48
-    assert lib.mspi_attn_fwd(ctypes.byref(a), p, p, p, p, None) == -1
-    assert b"head_dim" in lib.mspi_last_error()
+    a.D = a.Dv = 48
+    assert lib.mspi_attn_fwd(ctypes.byref(a), p, p, p, None, None, None, p, None) == -1
+    assert b"not in" in lib.mspi_last_error()
 
 
 def test_missing_library_is_loud(monkeypatch, tmp_path):

@@ -198,6 +198,53 @@ def test_attention(dev, B, H, N, D):
     _close(out.as_rows().view(B, N, C), ref, 2e-5, "attention")
 
 
+def test_attention_bias_mask(dev):
+    """Swin form: learned bias [heads,N,N] + per-window mask (0 / -100), both passed key-major."""
+    from mspi_amd import engine as E
+    B, H, N, D, nW = 6, 3, 98, 32, 3
+    g = torch.Generator().manual_seed(4)
+    qkv = torch.randn(B, N, 3 * H * D, generator=g)
+    bias = torch.randn(H, N, N, generator=g)
+    mask = torch.where(torch.rand(nW, N, N, generator=g) < 0.3, torch.tensor(-100.0), torch.tensor(0.0))
+    q, k, v = qkv.view(B, N, 3, H, D).permute(2, 0, 3, 1, 4).double()
+    att = (q @ k.transpose(-2, -1)) * D ** -0.5 + bias.double()[None] + mask.double()[torch.arange(B) % nW][:, None]
+    ref = (att.softmax(-1) @ v).transpose(1, 2).reshape(B, N, H * D).float()
+    xc = E.CL(qkv.to(dev).view(-1), 0, B, N, 1, 1, 3 * H * D, 3 * H * D)
+    out = E.attention(xc, B, N, H, D, D ** -0.5, biasT=bias.transpose(1, 2).contiguous().to(dev),
+                      maskT=mask.transpose(1, 2).contiguous().to(dev))
+    _close(out.as_rows().view(B, N, H * D), ref, 2e-5, "attention bias+mask")
+
+
+@pytest.mark.parametrize("q_thw,k_thw,heads", [((2, 6, 6), (2, 3, 3), 2), ((4, 7, 7), (4, 7, 7), 1), ((8, 14, 14), (8, 14, 14), 1)])
+def test_mvit_attention(dev, q_thw, k_thw, heads):
+    """Decomposed rel-pos (h, w, t) folded into the contraction + residual pooling vs the explicit formula."""
+    from mspi_amd import engine as E
+    hd, B = 96, 2
+    g = torch.Generator().manual_seed(sum(q_thw))
+    Nq, Nk = math.prod(q_thw), math.prod(k_thw)
+    q = torch.randn(B, Nq, heads * hd, generator=g)
+    k = torch.randn(B, Nk, heads * hd, generator=g)
+    v = torch.randn(B, Nk, heads * hd, generator=g)
+    Rt, Rh, Rw = (torch.randn(q_thw[i], k_thw[i], hd, generator=g) * 0.3 for i in range(3))
+    qh = q.view(B, Nq, heads, hd).transpose(1, 2).double()
+    kh = k.view(B, Nk, heads, hd).transpose(1, 2).double()
+    vh = v.view(B, Nk, heads, hd).transpose(1, 2).double()
+    rq = qh.reshape(B, heads, *q_thw, hd)
+    att = (qh * hd ** -0.5) @ kh.transpose(-2, -1)
+    att = (att.view(B, heads, *q_thw, *k_thw)
+           + torch.einsum("bythwc,hkc->bythwk", rq, Rh.double())[:, :, :, :, :, None, :, None]
+           + torch.einsum("bythwc,wkc->bythwk", rq, Rw.double())[:, :, :, :, :, None, None, :]
+           + torch.einsum("bythwc,tkc->bythwk", rq, Rt.double())[:, :, :, :, :, :, None, None]).view(B, heads, Nq, Nk)
+    ref = (att.softmax(-1) @ vh + qh).transpose(1, 2).reshape(B, Nq, heads * hd).float()
+
+    def cl(t, thw):
+        return E.CL(t.to(dev).contiguous().view(-1), 0, B, thw[0], thw[1], thw[2], heads * hd, heads * hd)
+
+    out = E.mvit_attention(cl(q, q_thw), cl(k, k_thw), cl(v, k_thw), B, heads, hd, hd ** -0.5, q_thw, k_thw,
+                           Rh.to(dev).contiguous(), Rw.to(dev).contiguous(), Rt.to(dev).contiguous())
+    _close(out.as_rows().view(B, Nq, heads * hd), ref, 2e-5, "mvit attention")
+
+
 def test_attention_large_logits(dev):
     """Forces the online-softmax rescale: one key tile late in the sequence dominates."""
     from mspi_amd import engine as E

@@ -56,6 +56,23 @@ def test_slowfast_backbone(golden_dir):
         assert T.feature_error(f, g, "v%d" % (i + 1)) <= 1e-6
 
 
+def test_mvit_backbone(golden_dir):
+    from mspi_amd.backbones.MViT import MViT
+    from mspi_amd.config import cfg
+    g = _g(golden_dir, "mvit_backbone_224")
+    m = T.seeded(lambda: MViT(cfg.MODEL.MVIT2.PATH_CFG), int(g["seed"]))
+    sd = m.state_dict()
+    assert len(sd) == 394 and T.sd_checksum(sd) == int(g["sd_crc"])
+    # the product's resolved per-block geometry equals the table the oracle restates from the reference ctor
+    arch = [(b.attn.num_heads, b.attn.stride_q, b.attn.stride_kv) for b in m.blocks]
+    assert arch == R.MVIT_S_ARCH["blocks"]
+    clips, _ = T.synth_inputs(1, 16, 224, 224, seed=int(g["seed"]))
+    with torch.no_grad():
+        feats = R.mvit_forward(sd, clips, R.MVIT_S_ARCH)
+    for i, f in enumerate(feats):
+        assert T.feature_error(f, g, "v%d" % (i + 1)) <= 1e-6
+
+
 @pytest.mark.parametrize("wa", [111, 300])
 def test_resnet18_audio(golden_dir, wa):
     from mspi_amd.backbones.resnet import ResNet
@@ -80,7 +97,8 @@ def _model(g, name, cls):
     return cfg, sd, clips, audio
 
 
-@pytest.mark.parametrize("case,name", [("av_x3dl_64", "x3dl"), ("av_x3dl_224", "x3dl"), ("av_slowfast_64", "slowfast4x16")])
+@pytest.mark.parametrize("case,name", [("av_x3dl_64", "x3dl"), ("av_x3dl_224", "x3dl"), ("av_slowfast_64", "slowfast4x16"),
+                                       ("av_mvit_224", "mvitv2s")])
 def test_audio_visual_model(golden_dir, case, name):
     g = _g(golden_dir, case)
     cfg, sd, clips, audio = _model(g, name, "AudioVisualSaliencyModel")
