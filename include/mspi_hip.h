@@ -145,11 +145,15 @@ int mspi_layernorm_fwd(const float* x, int64_t ldx, int64_t sNx, float* y, int64
  * q/k/v/o (and res, with o's strides) are addressed as base + b*sB + h*sH + token*sT + d (d contiguous).
  * D = head dim of q/k, Dv = head dim of v/o; (D,Dv) in {(32,32),(64,64),(96,96),(128,128),(128,96),(160,96)}.
  * biasT / maskT (optional) are stored key-major ([.][Nk][Nq]).
+ * tok_idx (optional, [nwin][N] int32): windowed sequences -- sequence b is window b % nwin of sample b / nwin
+ * (strides sB then address the SAMPLE) and its token t lives at row tok_idx[b % nwin][t] of that sample, for
+ * q, k, v, res and o alike: Swin's cyclic shift, window partition, window reverse and un-shift
+ * (backbones/video_swin_transformer.py:61-87,245-268) become index arithmetic inside the kernel.
  * Replaces model/model_utils.py:102-106 (SyncBlock), backbones/MViT.py:1261-1301 (pooled attention, residual
  * pooling as `res`), backbones/video_swin_transformer.py:169-187 (window attention, bias table + shift mask).
  * ------------------------------------------------------------------------------------ */
 typedef struct MspiAttnDesc {
-  int32_t B, Hh, Nq, Nk, D, Dv, nmask;
+  int32_t B, Hh, Nq, Nk, D, Dv, nmask, nwin;
   int64_t q_sB, q_sH, q_sT;
   int64_t k_sB, k_sH, k_sT;
   int64_t v_sB, v_sH, v_sT;
@@ -158,7 +162,7 @@ typedef struct MspiAttnDesc {
 } MspiAttnDesc;
 
 int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float* k, const float* v, const float* res,
-                  const float* biasT, const float* maskT, float* o, mspi_stream_t stream);
+                  const float* biasT, const float* maskT, const int32_t* tok_idx, float* o, mspi_stream_t stream);
 
 /* MViTv2 decomposed relative positions folded into the attention contraction (backbones/MViT.py:905-997):
  *   qa[b,h,i,:] = [ scale*q_i | q_i.Rh[hq(i),0..kH) | q_i.Rw[wq(i),0..kW) | q_i.Rt[tq(i),0..kT) | 0 ]   (DA columns)
@@ -192,6 +196,11 @@ int mspi_maxpool_fwd(const MspiDwConvDesc* d, const float* x, float* y, mspi_str
 int mspi_upsample_fwd(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t NT, int32_t H,
                       int32_t W, int32_t C, int32_t factor, int32_t accumulate, int32_t act,
                       mspi_stream_t stream);
+
+/* 2x2 spatial space-to-depth of Swin's PatchMerging (backbones/video_swin_transformer.py:311-326):
+ * y[n,t,h,w, q*C + c] = x[n,t,2h+dh(q),2w+dw(q),c] with (dh,dw)(q) = (0,0),(1,0),(0,1),(1,1).  H, W even. */
+int mspi_space_to_depth(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t NT, int32_t H, int32_t W,
+                        int32_t C, mspi_stream_t stream);
 
 /* SA gating x*m + x (model/model_utils.py:167-170): x[m,:] *= (1 + mask[m]), in place. */
 int mspi_rowgate(float* x, int64_t ldx, const float* mask, int64_t M, int32_t C, mspi_stream_t stream);

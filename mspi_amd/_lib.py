@@ -48,7 +48,7 @@ class DwConvDesc(C.Structure):
 class AttnDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("Hh", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("D", C.c_int32),
-        ("Dv", C.c_int32), ("nmask", C.c_int32),
+        ("Dv", C.c_int32), ("nmask", C.c_int32), ("nwin", C.c_int32),
         ("q_sB", C.c_int64), ("q_sH", C.c_int64), ("q_sT", C.c_int64),
         ("k_sB", C.c_int64), ("k_sH", C.c_int64), ("k_sT", C.c_int64),
         ("v_sB", C.c_int64), ("v_sH", C.c_int64), ("v_sT", C.c_int64),
@@ -79,7 +79,8 @@ _SIGNATURES = {
     "mspi_se_gate": (C.c_int, [_P, C.c_int32, C.c_float, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mspi_layernorm_fwd": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P, _P, C.c_float, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, _P, _P]),
-    "mspi_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mspi_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mspi_space_to_depth": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mspi_mvit_qk_augment": (C.c_int, [C.POINTER(MvitAugDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "mspi_maxpool_fwd": (C.c_int, [C.POINTER(DwConvDesc), _P, _P, _P]),
     "mspi_upsample_fwd": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

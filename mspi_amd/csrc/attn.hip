@@ -26,8 +26,9 @@ struct AttnArgs {
   const float* res;    // optional, added to the output (o strides)
   const float* biasT;  // optional [Hh][Nk][Nq]: transposed additive bias (key-major so a lane row is coalesced)
   const float* maskT;  // optional [nmask][Nk][Nq]: additive mask, sequence b uses slice b % nmask
+  const int* tok_idx;  // optional [nwin][N]: token t of sequence (sample, win) lives at row tok_idx[win][t] of the sample
   float* o;
-  int B, Hh, Nq, Nk, nmask;
+  int B, Hh, Nq, Nk, nmask, nwin;
   long q_sB, q_sH, q_sT, k_sB, k_sH, k_sT, v_sB, v_sH, v_sT, o_sB, o_sH, o_sT;
   float scale;
 };
@@ -49,10 +50,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   const int b = blockIdx.y / p.Hh, h = blockIdx.y % p.Hh;
   const int q = blockIdx.x * 128 + wave * 32 + li;
   const bool qok = q < p.Nq;
+  // windowed sequences (Swin): b = sample * nwin + win; rows are looked up, so the cyclic shift, the window
+  // partition and their inverses are pure index arithmetic -- no gather / scatter pass over the activations
+  const int sample = p.tok_idx ? b / p.nwin : b;
+  const int* tix = p.tok_idx ? p.tok_idx + (long)(b % p.nwin) * p.Nk : nullptr;
+  const int qrow = qok ? (tix ? tix[q] : q) : 0;
 
   float4 qr[NC];
   {
-    const float* qp = p.q + (long)b * p.q_sB + (long)h * p.q_sH + (long)(qok ? q : 0) * p.q_sT;
+    const float* qp = p.q + (long)sample * p.q_sB + (long)h * p.q_sH + (long)qrow * p.q_sT;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -68,21 +74,23 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const float* kb = p.k + (long)b * p.k_sB + (long)h * p.k_sH;
-  const float* vb = p.v + (long)b * p.v_sB + (long)h * p.v_sH;
+  const float* kb = p.k + (long)sample * p.k_sB + (long)h * p.k_sH;
+  const float* vb = p.v + (long)sample * p.v_sB + (long)h * p.v_sH;
 
   for (int k0 = 0; k0 < p.Nk; k0 += 32) {
     __syncthreads();  // previous tile fully consumed
     for (int idx = tid; idx < 32 * (D / 4); idx += 256) {
       const int row = idx / (D / 4), c4 = idx - row * (D / 4);
       const bool ok = k0 + row < p.Nk;
-      const float4 kv = *reinterpret_cast<const float4*>(kb + (ok ? (long)(k0 + row) * p.k_sT + c4 * 4 : 0));
+      const int kr = ok ? (tix ? tix[k0 + row] : k0 + row) : 0;
+      const float4 kv = *reinterpret_cast<const float4*>(kb + (ok ? (long)kr * p.k_sT + c4 * 4 : 0));
       *reinterpret_cast<float4*>(&Ks[row * LDD + c4 * 4]) = ok ? kv : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int idx = tid; idx < 32 * (DV / 4); idx += 256) {
       const int row = idx / (DV / 4), c4 = idx - row * (DV / 4);
       const bool ok = k0 + row < p.Nk;
-      const float4 vv = *reinterpret_cast<const float4*>(vb + (ok ? (long)(k0 + row) * p.v_sT + c4 * 4 : 0));
+      const int kr = ok ? (tix ? tix[k0 + row] : k0 + row) : 0;
+      const float4 vv = *reinterpret_cast<const float4*>(vb + (ok ? (long)kr * p.v_sT + c4 * 4 : 0));
       *reinterpret_cast<float4*>(&Vs[row * LDV + c4 * 4]) = ok ? vv : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 
   if (qok) {
     const float inv = 1.f / l_run;
-    const long oo = (long)b * p.o_sB + (long)h * p.o_sH + (long)q * p.o_sT;
+    const long oo = (long)sample * p.o_sB + (long)h * p.o_sH + (long)qrow * p.o_sT;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -263,7 +271,8 @@ extern "C" int mspi_mvit_qk_augment(const MspiMvitAugDesc* d, const float* q, co
 }
 
 extern "C" int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float* k, const float* v, const float* res,
-                             const float* biasT, const float* maskT, float* o, mspi_stream_t stream) {
+                             const float* biasT, const float* maskT, const int32_t* tok_idx, float* o,
+                             mspi_stream_t stream) {
   MSPI_REQUIRE(d && q && k && v && o, "mspi_attn_fwd: null argument");
   MSPI_REQUIRE(d->B > 0 && d->Hh > 0 && d->Nq > 0 && d->Nk > 0, "mspi_attn_fwd: empty extent");
   const int64_t st[12] = {d->q_sB, d->q_sH, d->q_sT, d->k_sB, d->k_sH, d->k_sT, d->v_sB, d->v_sH, d->v_sT, d->o_sB, d->o_sH, d->o_sT};
@@ -272,9 +281,12 @@ extern "C" int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float*
                "mspi_attn_fwd: pointers must be 16-B aligned");
   MSPI_REQUIRE((long)d->B * d->Hh < 65536, "mspi_attn_fwd: B*H too large");
   MSPI_REQUIRE(!maskT || d->nmask > 0, "mspi_attn_fwd: mask needs nmask > 0");
+  MSPI_REQUIRE(!tok_idx || (d->nwin > 0 && d->B % d->nwin == 0 && d->Nq == d->Nk),
+               "mspi_attn_fwd: a token index needs nwin > 0, B %% nwin == 0 and Nq == Nk");
   AttnArgs a;
-  a.q = q; a.k = k; a.v = v; a.res = res; a.biasT = biasT; a.maskT = maskT; a.o = o;
+  a.q = q; a.k = k; a.v = v; a.res = res; a.biasT = biasT; a.maskT = maskT; a.tok_idx = tok_idx; a.o = o;
   a.B = d->B; a.Hh = d->Hh; a.Nq = d->Nq; a.Nk = d->Nk; a.nmask = d->nmask > 0 ? d->nmask : 1;
+  a.nwin = d->nwin > 0 ? d->nwin : 1;
   a.q_sB = d->q_sB; a.q_sH = d->q_sH; a.q_sT = d->q_sT;
   a.k_sB = d->k_sB; a.k_sH = d->k_sH; a.k_sT = d->k_sT;
   a.v_sB = d->v_sB; a.v_sH = d->v_sH; a.v_sT = d->v_sT;

@@ -161,6 +161,26 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
   }
 }
 
+// ------------------------------------------------------------------ PatchMerging gather (2x2 space-to-depth)
+__global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy,
+                                                  int NT, int H, int W, int CV) {
+  const int Ho = H / 2, Wo = W / 2;
+  const long total = (long)NT * Ho * Wo * 4 * CV;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int cv = (int)(idx % CV);
+    long r = idx / CV;
+    const int qd = (int)(r & 3);
+    r >>= 2;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const long nt = r / Ho;
+    const int dh = qd & 1, dw = qd >> 1;   // q = 0:(0,0) 1:(1,0) 2:(0,1) 3:(1,1)
+    const float4 v = *reinterpret_cast<const float4*>(x + ((nt * H + 2 * ho + dh) * W + 2 * wo + dw) * ldx + cv * 4);
+    *reinterpret_cast<float4*>(y + ((nt * Ho + ho) * Wo + wo) * ldy + (long)(qd * CV + cv) * 4) = v;
+  }
+}
+
 // ------------------------------------------------------------------ SA gate  x *= (1 + mask[row])
 __global__ __launch_bounds__(256) void rowgate_kernel(float* __restrict__ x, long ldx, const float* __restrict__ mask,
                                                       long M, int CV) {
@@ -306,6 +326,17 @@ extern "C" int mspi_upsample_fwd(const float* src, int64_t lds, float* dst, int6
   hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, (long)lds, dst,
                      (long)ldd, NT, H, W, C / 4, factor, accumulate, act);
   return check_launch("mspi_upsample_fwd");
+}
+
+extern "C" int mspi_space_to_depth(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t NT, int32_t H, int32_t W,
+                                   int32_t C, mspi_stream_t stream) {
+  MSPI_REQUIRE(x && y && NT > 0 && H > 0 && W > 0 && C > 0, "mspi_space_to_depth: bad argument");
+  MSPI_REQUIRE((H & 1) == 0 && (W & 1) == 0, "mspi_space_to_depth: H and W must be even (PatchMerging pads odd sizes; not supported)");
+  MSPI_REQUIRE((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= 4 * C && aligned16(x) && aligned16(y),
+               "mspi_space_to_depth: C/ld multiples of 4, 16-B alignment");
+  hipLaunchKernelGGL(s2d_kernel, dim3(grid_for((long)NT * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, y,
+                     (long)ldy, NT, H, W, C / 4);
+  return check_launch("mspi_space_to_depth");
 }
 
 extern "C" int mspi_rowgate(float* x, int64_t ldx, const float* mask, int64_t M, int32_t C, mspi_stream_t stream) {

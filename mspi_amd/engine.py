@@ -388,10 +388,12 @@ def layernorm(x, gamma, beta, eps, out=None, act=ACT_NONE, table=None):
     return out
 
 
-def attention(qkv, B, Ntok, heads, hd, scale, out=None, biasT=None, maskT=None):
+def attention(qkv, B, Ntok, heads, hd, scale, out=None, biasT=None, maskT=None, tok_idx=None):
     """qkv: CL with rows (b, token) and 3*heads*hd columns laid out [3][heads][hd]
     (what `qkv.reshape(B,N,3,h,hd)` means, model/model_utils.py:100).  B sequences of Ntok tokens.
-    biasT [heads][Ntok][Ntok] / maskT [nmask][Ntok][Ntok]: key-major additive terms (Swin)."""
+    biasT [heads][Ntok][Ntok] / maskT [nmask][Ntok][Ntok]: key-major additive terms (Swin).
+    tok_idx int32 [nwin][Ntok]: the B = samples*nwin sequences are windows whose token t sits at row
+    tok_idx[win][t] of its sample (shifted-window attention without gather/scatter passes)."""
     lib = _lib.load()
     Cc = heads * hd
     assert qkv.C == 3 * Cc and qkv.M == B * Ntok and qkv.dense
@@ -400,16 +402,30 @@ def attention(qkv, B, Ntok, heads, hd, scale, out=None, biasT=None, maskT=None):
     d = AttnDesc()
     d.B, d.Hh, d.Nq, d.Nk, d.D, d.Dv = B, heads, Ntok, Ntok, hd, hd
     d.nmask = 0 if maskT is None else maskT.shape[0]
-    d.q_sB = d.k_sB = d.v_sB = Ntok * qkv.ld
+    d.nwin = 0 if tok_idx is None else tok_idx.shape[0]
+    rows_per_sample = Ntok * max(d.nwin, 1)
+    d.q_sB = d.k_sB = d.v_sB = rows_per_sample * qkv.ld
     d.q_sH = d.k_sH = d.v_sH = hd
     d.q_sT = d.k_sT = d.v_sT = qkv.ld
-    d.o_sB, d.o_sH, d.o_sT = Ntok * out.ld, hd, out.ld
+    d.o_sB, d.o_sH, d.o_sT = rows_per_sample * out.ld, hd, out.ld
     d.scale = float(scale)
     base = qkv.ptr
     with _Timed("attention", 4.0 * B * heads * Ntok * Ntok * hd, 16.0 * B * Ntok * Cc, "B=%d h=%d N=%d d=%d" % (B, heads, Ntok, hd)):
         check(lib.mspi_attn_fwd(C.byref(d), base, base + 4 * Cc, base + 8 * Cc, None,
                                 biasT.data_ptr() if biasT is not None else None,
-                                maskT.data_ptr() if maskT is not None else None, out.ptr, _stream()), "mspi_attn_fwd")
+                                maskT.data_ptr() if maskT is not None else None,
+                                tok_idx.data_ptr() if tok_idx is not None else None, out.ptr, _stream()), "mspi_attn_fwd")
+    return out
+
+
+def space_to_depth(x, out=None):
+    """Swin PatchMerging gather: [N,T,H,W,C] -> [N,T,H/2,W/2,4C], quadrant order (0,0),(1,0),(0,1),(1,1)."""
+    lib = _lib.load()
+    assert x.dense and x.C % 4 == 0
+    if out is None:
+        out = alloc(x.N, x.T, x.H // 2, x.W // 2, 4 * x.C, x.buf.device)
+    with _Timed("space_to_depth", 0.0, 8.0 * x.M * x.C):
+        check(lib.mspi_space_to_depth(x.ptr, x.ld, out.ptr, out.ld, x.N * x.T, x.H, x.W, x.C, _stream()), "mspi_space_to_depth")
     return out
 
 
@@ -446,8 +462,8 @@ def mvit_attention(q, k, v, B, heads, hd, scale, q_thw, k_thw, Rh, Rw, Rt, out=N
     assert q.ld == out.ld and q.dense and out.dense   # residual pooling reads q with o's strides
     with _Timed("attention", 2.0 * B * heads * Nq * Nk * (DA + hd), 4.0 * B * heads * (Nq * (DA + 2 * hd) + Nk * (DA + hd)),
                 "B=%d h=%d Nq=%d Nk=%d d=%d+%d" % (B, heads, Nq, Nk, DA, hd)):
-        check(lib.mspi_attn_fwd(C.byref(d), qa.data_ptr(), ka.data_ptr(), v.ptr, q.ptr, None, None, out.ptr, _stream()),
-              "mspi_attn_fwd")
+        check(lib.mspi_attn_fwd(C.byref(d), qa.data_ptr(), ka.data_ptr(), v.ptr, q.ptr, None, None, None, out.ptr,
+                                _stream()), "mspi_attn_fwd")
     return out
 
 

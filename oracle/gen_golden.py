@@ -166,6 +166,30 @@ def case_mvit_backbone(size=224, seed=0):
     _save("mvit_backbone_%d" % size, seed=seed, size=size, batch=1, sd_crc=T.sd_checksum(sd), **_feat_fixture(feats))
 
 
+def case_swin_backbone(seed=0):
+    """Swin-T depths through the reference class keeps the CPU forward short; Swin-S differs only in
+    the number of stage-2 blocks.  224x224 (no padding anywhere)."""
+    from mspi_amd.backbones.video_swin_transformer import SwinTransformer3D
+    prod = T.seeded(lambda: SwinTransformer3D(depths=[2, 2, 6, 2]), seed)
+    sd = prod.state_dict()
+    rh.with_config("videoswins")
+    from backbones.video_swin_transformer import SwinTransformer3D as RefSwin
+    ref = RefSwin(depths=[2, 2, 6, 2])
+    ref.eval()                       # the reference's train() override returns None
+    ref.load_state_dict(sd, strict=True)
+    clips, _ = T.synth_inputs(1, 16, 224, 224, seed=seed)
+    with torch.no_grad():
+        feats = ref(clips)
+        ora = R.swin_forward(sd, clips)
+    _check_restatement("swin-T backbone", feats, ora, 5e-5)
+    _save("swin_t_backbone_224", seed=seed, size=224, batch=1, sd_crc=T.sd_checksum(sd), **_feat_fixture(feats))
+
+
+def case_av_swin_224():
+    """Full AV model with the reference's default SwinTransformer3D() = Swin-S."""
+    _model_case("videoswins", "AudioVisualSaliencyModel", 224, 1, 111, 0, "av_swin_s_224")
+
+
 def case_av_mvit_224():
     _model_case("mvitv2s", "AudioVisualSaliencyModel", 224, 1, 111, 0, "av_mvit_224")
 

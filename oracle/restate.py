@@ -215,6 +215,89 @@ def mvit_forward(sd, clips, arch, prefix=""):
     return feats
 
 
+# ------------------------------------------------------------------------------- Video Swin
+def _swin_window_size(x_size, window, shift):
+    ws, ss = list(window), list(shift)
+    for i in range(3):
+        if x_size[i] <= window[i]:
+            ws[i], ss[i] = x_size[i], 0
+    return tuple(ws), tuple(ss)
+
+
+def _swin_partition(x, ws):
+    B, D, H, W, Cc = x.shape
+    x = x.view(B, D // ws[0], ws[0], H // ws[1], ws[1], W // ws[2], ws[2], Cc)
+    return x.permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(-1, ws[0] * ws[1] * ws[2], Cc)
+
+
+def _swin_mask(D, H, W, ws, ss):
+    """compute_mask, backbones/video_swin_transformer.py:333-346."""
+    img = torch.zeros(1, D, H, W, 1)
+    cnt = 0
+    for d in (slice(-ws[0]), slice(-ws[0], -ss[0]), slice(-ss[0], None)):
+        for h in (slice(-ws[1]), slice(-ws[1], -ss[1]), slice(-ss[1], None)):
+            for w in (slice(-ws[2]), slice(-ws[2], -ss[2]), slice(-ss[2], None)):
+                img[:, d, h, w, :] = cnt
+                cnt += 1
+    mw = _swin_partition(img, ws).squeeze(-1)
+    am = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0)
+
+
+def swin_block(sd, p, x, heads, window, shift, mask):
+    """SwinTransformerBlock3D + WindowAttention3D (backbones/video_swin_transformer.py:108-293); no padding case."""
+    B, D, H, W, Cc = x.shape
+    ws, ss = _swin_window_size((D, H, W), window, shift)
+    assert D % ws[0] == 0 and H % ws[1] == 0 and W % ws[2] == 0
+    h = _ln(sd, p + ".norm1", x)
+    shifted = any(i > 0 for i in ss)
+    if shifted:
+        h = torch.roll(h, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
+    xw = _swin_partition(h, ws)
+    B_, N, _ = xw.shape
+    qkv = _lin(sd, p + ".attn.qkv", xw).reshape(B_, N, 3, heads, Cc // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * (Cc // heads) ** -0.5, qkv[1], qkv[2]
+    attn = q @ k.transpose(-2, -1)
+    idx = sd[p + ".attn.relative_position_index"][:N, :N].reshape(-1)
+    bias = sd[p + ".attn.relative_position_bias_table"][idx].reshape(N, N, -1).permute(2, 0, 1)
+    attn = attn + bias.unsqueeze(0)
+    if shifted:
+        nW = mask.shape[0]
+        attn = (attn.view(B_ // nW, nW, heads, N, N) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, N, N)
+    o = _lin(sd, p + ".attn.proj", (attn.softmax(-1) @ v).transpose(1, 2).reshape(B_, N, Cc))
+    o = o.view(B, D // ws[0], H // ws[1], W // ws[2], ws[0], ws[1], ws[2], Cc).permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, D, H, W, Cc)
+    if shifted:
+        o = torch.roll(o, shifts=ss, dims=(1, 2, 3))
+    x = x + o
+    return x + _lin(sd, p + ".mlp.fc2", F.gelu(_lin(sd, p + ".mlp.fc1", _ln(sd, p + ".norm2", x))))
+
+
+def swin_forward(sd, clips, prefix="", window=(8, 7, 7), heads=(3, 6, 12, 24)):
+    """SwinTransformer3D.forward, backbones/video_swin_transformer.py:692-708: every stage's pre-merge output."""
+    p = prefix
+    w = sd[p + "patch_embed.proj.weight"]
+    x = F.conv3d(clips, w, sd[p + "patch_embed.proj.bias"], w.shape[2:]).permute(0, 2, 3, 4, 1)
+    shift = tuple(i // 2 for i in window)
+    feats = []
+    li = 0
+    while "%slayers.%d.blocks.0.norm1.weight" % (p, li) in sd:
+        B, D, H, W, Cc = x.shape
+        ws, ss = _swin_window_size((D, H, W), window, shift)
+        mask = _swin_mask(D, H, W, ws, ss)
+        bi = 0
+        while "%slayers.%d.blocks.%d.norm1.weight" % (p, li, bi) in sd:
+            x = swin_block(sd, "%slayers.%d.blocks.%d" % (p, li, bi), x, heads[li], window,
+                           (0, 0, 0) if bi % 2 == 0 else shift, mask)
+            bi += 1
+        feats.append(x.permute(0, 4, 1, 2, 3))
+        q = "%slayers.%d.downsample" % (p, li)
+        if q + ".reduction.weight" in sd:   # PatchMerging :296-329 (even grids)
+            x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
+            x = _lin(sd, q + ".reduction", _ln(sd, q + ".norm", x))
+        li += 1
+    return feats
+
+
 # ------------------------------------------------------------------------------- audio ResNet-18
 def resnet18_forward(sd, x, prefix=""):
     """backbones/resnet.py:57-143 (1-channel stem, BasicBlock x [2,2,2,2], returns layer4 map)."""
@@ -428,6 +511,7 @@ MVIT_S_ARCH = {   # configs/MVITv2_S_16x4.yaml resolved the way MViT.__init__ do
               + [(4, (1, 1, 1), (1, 2, 2))] * 10 + [(8, (1, 2, 2), (1, 1, 1)), (8, (1, 1, 1), (1, 1, 1))],
 }
 BACKBONES["mvitv2s"] = lambda sd, x, prefix: mvit_forward(sd, x[0], MVIT_S_ARCH, prefix)
+BACKBONES["videoswins"] = lambda sd, x, prefix: swin_forward(sd, x, prefix)
 
 
 def audio_visual_forward(sd, clips, audios, name, lateral_bool, lateral_stride, num_frames=16):

@@ -46,7 +46,7 @@ def test_descriptor_validation_without_gpu():
     a = _lib.AttnDesc()
     a.B = a.Hh = a.Nq = a.Nk = 1
     a.D = a.Dv = 48
-    assert lib.mspi_attn_fwd(ctypes.byref(a), p, p, p, None, None, None, p, None) == -1
+    assert lib.mspi_attn_fwd(ctypes.byref(a), p, p, p, None, None, None, None, p, None) == -1
     assert b"not in" in lib.mspi_last_error()
 
 

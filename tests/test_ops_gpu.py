@@ -215,6 +215,37 @@ def test_attention_bias_mask(dev):
     _close(out.as_rows().view(B, N, H * D), ref, 2e-5, "attention bias+mask")
 
 
+def test_windowed_attention_and_space_to_depth(dev):
+    """Shifted-window attention through the token index (no gather pass) vs roll + partition + reverse in torch."""
+    from mspi_amd import engine as E
+    from mspi_amd.backbones import video_swin_transformer as S
+    B, D, H, W, heads, hd = 2, 4, 14, 14, 3, 32
+    ws, ss = (4, 7, 7), (0, 3, 3)
+    Cc = heads * hd
+    g = torch.Generator().manual_seed(6)
+    qkv = torch.randn(B, D, H, W, 3 * Cc, generator=g)
+    N = ws[0] * ws[1] * ws[2]
+    bias = torch.randn(heads, N, N, generator=g)
+    mask = S.compute_mask(D, H, W, ws, ss)
+    sh = torch.roll(qkv, (-ss[0], -ss[1], -ss[2]), (1, 2, 3))
+    xw = sh.view(B, D // ws[0], ws[0], H // ws[1], ws[1], W // ws[2], ws[2], 3 * Cc).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(-1, N, 3 * Cc)
+    q, k, v = xw.view(-1, N, 3, heads, hd).permute(2, 0, 3, 1, 4).double()
+    nW = mask.shape[0]
+    att = (q @ k.transpose(-2, -1)) * hd ** -0.5 + bias.double()[None]
+    att = (att.view(B, nW, heads, N, N) + mask.double()[None, :, None]).view(-1, heads, N, N)
+    o = (att.softmax(-1) @ v).transpose(1, 2).reshape(-1, N, Cc).float()
+    o = o.view(B, D // ws[0], H // ws[1], W // ws[2], ws[0], ws[1], ws[2], Cc).permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, D, H, W, Cc)
+    ref = torch.roll(o, ss, (1, 2, 3))
+    xc = E.CL(qkv.to(dev).contiguous().view(-1), 0, B, D, H, W, 3 * Cc, 3 * Cc)
+    out = E.attention(xc, B * nW, N, heads, hd, hd ** -0.5, biasT=bias.transpose(1, 2).contiguous().to(dev),
+                      maskT=mask.transpose(1, 2).contiguous().to(dev), tok_idx=S.window_token_index(D, H, W, ws, ss).to(dev))
+    _close(out.as_ncdhw().permute(0, 2, 3, 4, 1), ref, 2e-5, "windowed attention")
+    x = torch.randn(2, 96, 3, 6, 8, generator=g)
+    xl = x.permute(0, 2, 3, 4, 1)
+    refm = torch.cat([xl[:, :, 0::2, 0::2], xl[:, :, 1::2, 0::2], xl[:, :, 0::2, 1::2], xl[:, :, 1::2, 1::2]], -1)
+    _close(E.space_to_depth(_cl(x, dev)).as_ncdhw().permute(0, 2, 3, 4, 1), refm, 0, "space_to_depth")
+
+
 @pytest.mark.parametrize("q_thw,k_thw,heads", [((2, 6, 6), (2, 3, 3), 2), ((4, 7, 7), (4, 7, 7), 1), ((8, 14, 14), (8, 14, 14), 1)])
 def test_mvit_attention(dev, q_thw, k_thw, heads):
     """Decomposed rel-pos (h, w, t) folded into the contraction + residual pooling vs the explicit formula."""

@@ -73,6 +73,32 @@ def test_mvit_backbone(golden_dir):
         assert T.feature_error(f, g, "v%d" % (i + 1)) <= 1e-6
 
 
+def test_swin_backbone(golden_dir):
+    from mspi_amd.backbones.video_swin_transformer import SwinTransformer3D
+    g = _g(golden_dir, "swin_t_backbone_224")
+    m = T.seeded(lambda: SwinTransformer3D(depths=[2, 2, 6, 2]), int(g["seed"]))
+    sd = m.state_dict()
+    assert T.sd_checksum(sd) == int(g["sd_crc"])
+    assert len(SwinTransformer3D().state_dict()) == 349                      # default = Swin-S
+    clips, _ = T.synth_inputs(1, 16, 224, 224, seed=int(g["seed"]))
+    with torch.no_grad():
+        feats = R.swin_forward(sd, clips)
+    for i, f in enumerate(feats):
+        assert T.feature_error(f, g, "v%d" % (i + 1)) <= 1e-6
+
+
+def test_swin_index_and_mask_helpers():
+    """The product's window index / mask helpers against roll + window_partition done with torch."""
+    from mspi_amd.backbones import video_swin_transformer as S
+    D, H, W, ws, ss = 4, 14, 14, (4, 7, 7), (0, 3, 3)
+    x = torch.arange(D * H * W, dtype=torch.float32).view(1, D, H, W, 1)
+    ref = R._swin_partition(torch.roll(x, (-ss[0], -ss[1], -ss[2]), (1, 2, 3)), ws).squeeze(-1).to(torch.int32)
+    assert torch.equal(S.window_token_index(D, H, W, ws, ss), ref)
+    assert torch.equal(S.compute_mask(D, H, W, ws, ss), R._swin_mask(D, H, W, ws, ss))
+    assert S.get_window_size((8, 56, 56), (8, 7, 7), (4, 3, 3)) == ((8, 7, 7), (0, 3, 3))
+    assert S.get_window_size((8, 7, 7), (8, 7, 7), (4, 3, 3)) == ((8, 7, 7), (0, 0, 0))
+
+
 @pytest.mark.parametrize("wa", [111, 300])
 def test_resnet18_audio(golden_dir, wa):
     from mspi_amd.backbones.resnet import ResNet
@@ -98,7 +124,7 @@ def _model(g, name, cls):
 
 
 @pytest.mark.parametrize("case,name", [("av_x3dl_64", "x3dl"), ("av_x3dl_224", "x3dl"), ("av_slowfast_64", "slowfast4x16"),
-                                       ("av_mvit_224", "mvitv2s")])
+                                       ("av_mvit_224", "mvitv2s"), ("av_swin_s_224", "videoswins")])
 def test_audio_visual_model(golden_dir, case, name):
     g = _g(golden_dir, case)
     cfg, sd, clips, audio = _model(g, name, "AudioVisualSaliencyModel")

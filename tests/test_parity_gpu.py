@@ -60,6 +60,16 @@ def test_mvit_backbone_vs_golden(dev, golden_dir):
         assert T.feature_error(f, g, "v%d" % (i + 1)) < 2e-4, "v%d" % (i + 1)
 
 
+def test_swin_backbone_vs_golden(dev, golden_dir):
+    from mspi_amd.backbones.video_swin_transformer import SwinTransformer3D
+    g = _g(golden_dir, "swin_t_backbone_224")
+    m = T.seeded(lambda: SwinTransformer3D(depths=[2, 2, 6, 2]), int(g["seed"])).to(dev)
+    clips, _ = T.synth_inputs(1, 16, 224, 224, seed=int(g["seed"]), device=dev)
+    feats = m(clips)
+    for i, f in enumerate(feats):
+        assert T.feature_error(f, g, "v%d" % (i + 1)) < 2e-4, "v%d" % (i + 1)
+
+
 @pytest.mark.parametrize("wa", [111, 300])
 def test_resnet18_audio_vs_golden(dev, golden_dir, wa):
     from mspi_amd.backbones.resnet import ResNet
@@ -80,7 +90,7 @@ def _build(g, name, cls, dev):
 
 
 @pytest.mark.parametrize("case,name", [("av_x3dl_64", "x3dl"), ("av_x3dl_224", "x3dl"), ("av_slowfast_64", "slowfast4x16"),
-                                       ("av_mvit_224", "mvitv2s")])
+                                       ("av_mvit_224", "mvitv2s"), ("av_swin_s_224", "videoswins")])
 def test_audio_visual_model_vs_golden(dev, golden_dir, case, name):
     g = _g(golden_dir, case)
     cfg, m, clips, audio = _build(g, name, "AudioVisualSaliencyModel", dev)
