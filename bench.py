@@ -95,16 +95,9 @@ def main():
         sys.stdout = so
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model = model.to(dev)
-    if world > 1:   # weight fan-out: one flat RCCL broadcast from rank 0 (xGMI), then unflatten in place
-        tensors = [t for t in list(model.parameters()) + list(model.buffers()) if t.is_floating_point()]
-        flat = torch.cat([t.detach().reshape(-1) for t in tensors])
-        dist.broadcast(flat, 0)
-        off = 0
-        with torch.no_grad():
-            for t in tensors:
-                t.copy_(flat[off:off + t.numel()].view_as(t))
-                off += t.numel()
-        model._invalidate()
+    if world > 1:   # weight fan-out: one flat RCCL broadcast from rank 0 over xGMI
+        from mspi_amd.sharding import broadcast_weights
+        broadcast_weights(model, 0)
     clips, audio = T.synth_inputs(B, 16, S, S, Wa=args.wa, seed=100 + rank, device=dev)
 
     gathered = [torch.empty(B, S, S, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None

@@ -21,6 +21,7 @@
 #ifndef MSPI_HIP_H
 #define MSPI_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -215,6 +216,13 @@ int mspi_mean_rows(const float* x, int64_t ldx, int64_t rows_per_sample_stride, 
 /* out[0] (+)= scale * mean_n( -cos(p[n,:], z[n,:]) )   (D(), model/model_utils.py:285-290). */
 int mspi_neg_cosine(const float* p, const float* z, float* out, int32_t N, int32_t C, float scale,
                     int32_t accumulate, mspi_stream_t stream);
+
+/* Saliency-map post-processing (inference.py:66-69,85-89; OpenCV upstream -- parity unpinned):
+ * out[n] = uint8( round( 255 * minmax( resize_bilinear( exp( GaussianBlur11x11(logmap[n]) ), Ho x Wo ) ) ) ).
+ * workspace: mspi_postprocess_workspace(...) bytes of device memory. */
+size_t mspi_postprocess_workspace(int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo);
+int mspi_postprocess_u8(const float* logmap, unsigned char* out, void* workspace, int32_t N, int32_t H, int32_t W,
+                        int32_t Ho, int32_t Wo, mspi_stream_t stream);
 
 /* y = a + b over n floats (plain residual add where no producer can fuse it). */
 int mspi_add(const float* a, const float* b, float* y, int64_t n, mspi_stream_t stream);

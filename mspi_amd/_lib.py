@@ -90,6 +90,8 @@ _SIGNATURES = {
     "mspi_mean_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mspi_neg_cosine": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P]),
     "mspi_add": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "mspi_postprocess_workspace": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "mspi_postprocess_u8": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

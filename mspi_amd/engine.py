@@ -516,3 +516,17 @@ def add(a, b, y):
     lib = _lib.load()
     check(lib.mspi_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "mspi_add")
     return y
+
+
+def postprocess_u8(logmap, out_hw):
+    """[N,H,W] log-probability maps (GPU) -> uint8 [N,Ho,Wo] grey maps (GPU): blur, exp, resize, min-max, round."""
+    lib = _lib.load()
+    _need_gpu(logmap)
+    N, H, W = logmap.shape
+    Ho, Wo = out_hw
+    logmap = logmap.contiguous()
+    ws = torch.empty(lib.mspi_postprocess_workspace(N, H, W, Ho, Wo), dtype=torch.uint8, device=logmap.device)
+    out = torch.empty(N, Ho, Wo, dtype=torch.uint8, device=logmap.device)
+    check(lib.mspi_postprocess_u8(logmap.data_ptr(), out.data_ptr(), ws.data_ptr(), N, H, W, Ho, Wo, _stream()),
+          "mspi_postprocess_u8")
+    return out

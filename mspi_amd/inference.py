@@ -1,0 +1,244 @@
+"""Inference entry -- the MI355X counterpart of the reference's inference.py (functions :19-165, CLI :167-192).
+
+Same functions (`normalize, get_audio_feature, blur, process, inference_dataset, torch_transform`), same CLI
+flags, same output files `save_path/<video>/<frame name>`; what differs:
+  * the model forward and the map post-processing (blur -> exp -> resize -> min-max -> uint8) run on the GPU
+    through the C ABI; one uint8 map comes back per frame instead of an fp32 map + five OpenCV passes;
+  * sliding windows are independent, so `--batch` windows go through one forward;
+  * the wav is read and resampled once per video, not once per frame (inference.py:28-31 does it per window);
+  * videos are sharded over ranks when launched with torch.distributed.run (one process per GPU, no collective);
+  * cv2 / torchaudio / torchvision are not required: PIL does the frame decode + resize (what torchvision's
+    transforms do on PIL images), scipy reads the wav, and torchaudio's sinc resampler and Spectrogram are
+    restated on torch -- PARITY UNPINNED for those host-side third-party pieces;
+  * `--model` selects the motion encoder (upstream: edit config.py:59) and the SyncBlock token tables are sized
+    from `--resolution`, which removes the resolution/config mismatches F2 / F3 of SURVEY.md.
+
+  python -m mspi_amd.inference --weight w.pt --path_data ./AuViDataset --dataset AVAD --model x3dl
+"""
+import argparse
+import glob
+import math
+import os
+
+import numpy as np
+import torch
+
+IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+_RESOLUTION = [224, 384]     # (H, W) the frames are resized to; set from the CLI
+_AUDIO_CACHE = {}
+
+
+def normalize(img):
+    img = (img - img.min()) / (img.max() - img.min())
+    return img
+
+
+# ----------------------------------------------------------------------------- audio front end (host)
+def _sinc_resample(wave, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """torchaudio.transforms.Resample defaults ('sinc_interp_hann'), restated: a strided conv with a
+    Hann-windowed sinc kernel bank."""
+    orig_freq, new_freq = int(orig_freq), int(new_freq)
+    if orig_freq == new_freq:
+        return wave
+    g = math.gcd(orig_freq, new_freq)
+    orig, new = orig_freq // g, new_freq // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernel = torch.where(t == 0, torch.ones_like(t), torch.sin(t) / t) * window * (base / orig)
+    kernel = kernel.to(torch.float32)
+    n = wave.shape[-1]
+    x = torch.nn.functional.pad(wave[:, None], (width, width + orig))
+    y = torch.nn.functional.conv1d(x, kernel, stride=orig).transpose(1, 2).reshape(wave.shape[0], -1)
+    return y[..., : math.ceil(new * n / orig)]
+
+
+def _load_wav_16k(audio_path):
+    if audio_path not in _AUDIO_CACHE:
+        from scipy.io import wavfile
+        sr, data = wavfile.read(audio_path)
+        if data.dtype.kind == "i":
+            data = data.astype(np.float32) / float(2 ** (8 * data.dtype.itemsize - 1))
+        elif data.dtype.kind == "u":
+            data = (data.astype(np.float32) - 128.0) / 128.0
+        wave = torch.as_tensor(np.atleast_2d(data.T if data.ndim == 2 else data), dtype=torch.float32)
+        wave = _sinc_resample(wave, sr, 16000)
+        if wave.shape[0] == 2:
+            wave = torch.mean(wave, dim=0).unsqueeze(0)
+        _AUDIO_CACHE.clear()
+        _AUDIO_CACHE[audio_path] = wave
+    return _AUDIO_CACHE[audio_path]
+
+
+def get_audio_feature(audio_path, start_idx, fps, len_snippet=32, mode=False, num_frames=None):
+    """Log-spectrogram window [1,257,111] for the clip starting at frame `start_idx` (inference.py:24-63)."""
+    spectro_shape = (257, 111)
+    if os.path.exists(audio_path):
+        audio = _load_wav_16k(audio_path)
+        mm = 16000
+        if num_frames is not None:
+            mm = audio.shape[-1]
+            start = int(np.round((start_idx / num_frames * mm)))
+            end = int(np.round(((start_idx + len_snippet + 1) / num_frames * mm)))
+        else:
+            start = int(np.round((start_idx / float(fps)) * mm))
+            end = int(np.round(((start_idx + len_snippet + 1) / float(fps)) * mm))
+        audio = audio[:, start:end]
+        if mode:
+            audio = torch.flip(audio, [1])
+        # torchaudio.transforms.Spectrogram(n_fft=512, hop_length=160): hann window, centre + reflect pad, power 2
+        spec = torch.stft(audio, n_fft=512, hop_length=160, win_length=512, window=torch.hann_window(512), center=True,
+                          pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+        audio = torch.log(spec.abs().pow(2.0) + 1e-6)
+        means = audio.mean(dim=1, keepdim=True)
+        stds = audio.std(dim=1, keepdim=True)
+        aud = (audio - means) / (stds + 1e-6)
+        tmp = torch.zeros(1, spectro_shape[0], spectro_shape[1]) + 0.02
+        if audio.shape[-1] <= spectro_shape[1]:
+            tmp[:, :, : audio.shape[-1]] = aud
+            aud = tmp
+        else:
+            aud = aud[:, :, : spectro_shape[1]]
+    else:
+        aud = torch.zeros((1, spectro_shape[0], spectro_shape[1])) + 0.02
+    return aud
+
+
+def blur(img):
+    """Host Gaussian blur 11x11 (sigma 2.0, reflect-101) of a numpy map -- what cv2.GaussianBlur(img,(11,11),0)
+    computes.  `process` does not call it: the device post-process kernel blurs in place of it."""
+    k = np.exp(-(np.arange(11, dtype=np.float32) - 5) ** 2 / (2 * 2.0 ** 2))
+    k /= k.sum()
+    p = np.pad(np.asarray(img, dtype=np.float32), 5, mode="reflect")
+    p = np.stack([p[:, i:i + img.shape[1]] for i in range(11)], -1) @ k
+    return np.stack([p[i:i + img.shape[0]] for i in range(11)], -1) @ k
+
+
+@torch.no_grad()
+def process(model, frames, frame_idx, vname, img_size, audio_feature=None, args=None, labels=None):
+    """frames [B,3,T,H,W] (B sliding windows), frame_idx: list of B output file names.  Writes B maps."""
+    from . import engine as E
+    frames = frames.to(device, non_blocking=True)
+    if args.use_sound:
+        pred = model(frames, audio_feature.to(device, non_blocking=True))[0]
+    else:
+        pred = model(frames)[0]
+    maps = E.postprocess_u8(pred, (img_size[1], img_size[0])).cpu().numpy()      # img_size is (W, H) as in cv2.resize
+    from PIL import Image
+    os.makedirs(os.path.join(args.save_path, vname), exist_ok=True)
+    names = frame_idx if isinstance(frame_idx, (list, tuple)) else [frame_idx]
+    for name, m in zip(names, maps):
+        Image.fromarray(m).save(os.path.join(args.save_path, vname, name))
+
+
+def torch_transform(path):
+    """Resize to the model resolution, scale to [0,1], ImageNet-normalise (inference.py:154-165)."""
+    from PIL import Image
+    img = Image.open(path).convert("RGB")
+    sz = img.size
+    img = img.resize((_RESOLUTION[1], _RESOLUTION[0]), Image.BILINEAR)
+    t = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
+    mean = torch.tensor(IMAGENET_DEFAULT_MEAN).view(3, 1, 1)
+    std = torch.tensor(IMAGENET_DEFAULT_STD).view(3, 1, 1)
+    return (t - mean) / std, sz
+
+
+def _flush(model, batch, vname, img_size, args):
+    if not batch:
+        return
+    clips = torch.stack([b[0] for b in batch])
+    auds = torch.stack([b[1] for b in batch])
+    process(model, clips, [b[2] for b in batch], vname, img_size, audio_feature=auds, args=args)
+    batch.clear()
+
+
+def inference_dataset(model, args):
+    """Sliding 16-frame window, stride 1; the first 15 frames come from the time-reversed first windows
+    (inference.py:94-152)."""
+    len_temporal = args.clip_size
+    if args.dataset == "DIEM":
+        file_name = "DIEM_list_test_fps.txt"
+    else:
+        file_name = "{}_list_test_{}_fps.txt".format(args.dataset, args.split)
+    list_data, videos_fps = [], {}
+    with open(os.path.join(args.path_data, "fold_lists", file_name), "r") as f:
+        for line in f.readlines():
+            name, frame_num, fps = line.split(" ")
+            list_data.append(name)
+            videos_fps[name] = fps
+    list_data.sort()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    list_data = list_data[rank::world]            # videos are independent units: shard, no collective
+    print(list_data)
+    bs = max(1, getattr(args, "batch", 1))
+    for vname in list_data:
+        print("Processing: " + vname)
+        audio_path = os.path.join(args.path_data, "video_audio", args.dataset, vname, vname + ".wav")
+        list_frames = glob.glob(os.path.join(args.path_data, "video_frames", args.dataset, vname, "*.jpg"))
+        list_frames.sort(key=lambda x: int(os.path.basename(x).split(".")[0].split("_")[1]))
+        os.makedirs(os.path.join(args.save_path, vname), exist_ok=True)
+        if len(list_frames) < 2 * len_temporal - 1:
+            print("More frames are needed")
+            continue
+        snippet, batch = [], []
+        img_size = (640, 480)
+        for i in range(len(list_frames)):
+            img_tensor, _ = torch_transform(list_frames[i])
+            snippet.append(img_tensor)
+            if i >= len_temporal - 1:
+                clip = torch.stack(snippet).permute(1, 0, 2, 3)          # [3,T,H,W]
+                aud = get_audio_feature(audio_path=audio_path, start_idx=i - len_temporal + 1, fps=videos_fps[vname])
+                batch.append((clip, aud, os.path.basename(list_frames[i])))
+                if i < 2 * len_temporal - 2:      # first (len_temporal-1) frames: reversed clip + reversed audio
+                    aud_r = get_audio_feature(audio_path=audio_path, start_idx=i - len_temporal + 1,
+                                              fps=videos_fps[vname], mode=True)
+                    batch.append((torch.flip(clip, [1]), aud_r, os.path.basename(list_frames[i - len_temporal + 1])))
+                if len(batch) >= bs:
+                    _flush(model, batch, vname, img_size, args)
+                del snippet[0]
+        _flush(model, batch, vname, img_size, args)
+
+
+def build_model(model_name, resolution, wa=111, weight=None, use_sound=True):
+    """cfg for `model_name` with the SyncBlock tables sized for `resolution` / a 257 x wa spectrogram."""
+    from . import testing as T
+    from .model.model_utils import AudioVisualSaliencyModel, VisualSaliencyModel
+    t_tok = {"x3dl": 16, "slowfast4x16": 4}.get(model_name, 8)
+    cfg = T.make_cfg(model_name, num_aud_tokens=9 * ((wa + 31) // 32),
+                     num_vis_tokens=t_tok * (resolution[0] // 32) * (resolution[1] // 32))
+    cfg.DATA.RESOLUTION = tuple(resolution)
+    model = (AudioVisualSaliencyModel if use_sound else VisualSaliencyModel)(cfg=cfg)
+    if weight is not None and os.path.exists(weight):
+        model.load_state_dict(torch.load(weight, map_location="cpu"), strict=False)
+    return model.to(device).eval()
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--weight", default="./output/mvitv2_small_224_384_16_s2.pt", type=str)
+    parser.add_argument("--save_path", default="./output", type=str)
+    parser.add_argument("--split", default=2, type=int)
+    parser.add_argument("--path_data", default="./AuViDataset", type=str)
+    parser.add_argument("--dataset", default="AVAD", type=str)
+    parser.add_argument("--clip_size", default=16, type=int)
+    parser.add_argument("--use_sound", default=True, type=bool)
+    parser.add_argument("--model", default=os.environ.get("MSPI_MOTION_ENCODER", "mvitv2s"), type=str)
+    parser.add_argument("--resolution", default=[224, 384], type=int, nargs=2, help="H W the frames are resized to")
+    parser.add_argument("--batch", default=8, type=int, help="sliding windows per forward")
+    args = parser.parse_args()
+    print(args)
+    os.makedirs(args.save_path, exist_ok=True)
+    if not torch.cuda.is_available():
+        raise SystemExit("mspi_amd.inference needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    _RESOLUTION[:] = args.resolution
+    model = build_model(args.model, args.resolution, weight=args.weight, use_sound=args.use_sound)
+    inference_dataset(model, args)

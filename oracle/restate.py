@@ -541,3 +541,19 @@ def visual_forward(sd, clips, name, lateral_bool, lateral_stride, num_frames=16)
     masks = adapter(sd, "adapter", o1, o0, num_frames, num_frames // 4)
     feats = BACKBONES[name](sd, pack_clips(name, clips), "visnet.")
     return decode(sd, feats, masks, lateral_bool, lateral_stride), 0
+
+
+# ------------------------------------------------------------------------------- post-processing (host side upstream)
+def postprocess_u8(logmap, out_hw):
+    """inference.py:66-69,85-89 restated without OpenCV (absent here -> PARITY UNPINNED against cv2 itself):
+    cv2.GaussianBlur(11x11, sigma 0 -> 2.0, BORDER_REFLECT_101), np.exp, cv2.resize INTER_LINEAR
+    (pixel-centre aligned), min-max normalise, np.round(x*255).astype(uint8).  logmap: [H,W] float tensor."""
+    k = torch.exp(-(torch.arange(11, dtype=torch.float32) - 5) ** 2 / (2 * 2.0 ** 2))
+    k = k / k.sum()
+    x = logmap[None, None].float()
+    x = F.pad(x, (5, 5, 5, 5), mode="reflect")
+    x = F.conv2d(F.conv2d(x, k.view(1, 1, 1, 11)), k.view(1, 1, 11, 1))
+    x = torch.exp(x)
+    x = F.interpolate(x, size=out_hw, mode="bilinear", align_corners=False)[0, 0]
+    x = (x - x.min()) / (x.max() - x.min())
+    return torch.round(x * 255).to(torch.uint8)

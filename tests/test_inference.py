@@ -1,0 +1,111 @@
+"""inference.py surface: host-side front end on CPU; post-process kernel and the clip loop on the GPU."""
+import math
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+
+def _make_dataset(root, name="clip1", n_frames=34, hw=(48, 64), fps=25, sr=22050):
+    from PIL import Image
+    from scipy.io import wavfile
+    rng = np.random.RandomState(0)
+    fdir = os.path.join(root, "video_frames", "TOY", name)
+    adir = os.path.join(root, "video_audio", "TOY", name)
+    os.makedirs(fdir), os.makedirs(adir), os.makedirs(os.path.join(root, "fold_lists"))
+    for i in range(n_frames):
+        Image.fromarray(rng.randint(0, 255, (hw[0], hw[1], 3), dtype=np.uint8)).save(os.path.join(fdir, "img_%05d.jpg" % (i + 1)))
+    t = np.arange(int(sr * n_frames / fps) + sr) / sr
+    wav = (0.3 * np.sin(2 * np.pi * 440 * t) + 0.1 * rng.randn(t.size)).astype(np.float32)
+    wavfile.write(os.path.join(adir, name + ".wav"), sr, np.stack([wav, 0.5 * wav], 1))     # stereo
+    with open(os.path.join(root, "fold_lists", "TOY_list_test_2_fps.txt"), "w") as f:
+        f.write("%s %d %d\n" % (name, n_frames, fps))
+    return os.path.join(adir, name + ".wav")
+
+
+def test_audio_front_end(tmp_path):
+    from mspi_amd import inference as I
+    wav = _make_dataset(str(tmp_path))
+    a = I.get_audio_feature(wav, start_idx=3, fps=25)
+    assert tuple(a.shape) == (1, 257, 111) and torch.isfinite(a).all()
+    assert a.mean(1).abs().max() < 1e-4                       # per time-column standardised over the 257 bins
+    r = I.get_audio_feature(wav, start_idx=3, fps=25, mode=True)
+    assert not torch.allclose(a, r)
+    assert torch.allclose(I.get_audio_feature(str(tmp_path / "missing.wav"), 0, 25), torch.full((1, 257, 111), 0.02))
+    # sinc resampler: a 1 kHz tone survives 48 kHz -> 16 kHz
+    t = torch.arange(48000) / 48000.0
+    y = I._sinc_resample(torch.sin(2 * math.pi * 1000 * t)[None], 48000, 16000)
+    ref = torch.sin(2 * math.pi * 1000 * torch.arange(16000) / 16000.0)
+    assert y.shape[-1] == 16000 and (y[0, 200:-200] - ref[200:-200]).abs().max() < 2e-3
+
+
+def test_blur_and_transform(tmp_path):
+    from mspi_amd import inference as I
+    from oracle import restate as R
+    _make_dataset(str(tmp_path))
+    x = torch.randn(40, 52)
+    k = torch.exp(-(torch.arange(11.0) - 5) ** 2 / 8)
+    k = k / k.sum()
+    ref = torch.nn.functional.conv2d(torch.nn.functional.conv2d(torch.nn.functional.pad(x[None, None], (5, 5, 5, 5), mode="reflect"),
+                                                                k.view(1, 1, 1, 11)), k.view(1, 1, 11, 1))[0, 0]
+    assert np.abs(I.blur(x.numpy()) - ref.numpy()).max() < 1e-5
+    I._RESOLUTION[:] = [32, 48]
+    img, sz = I.torch_transform(os.path.join(str(tmp_path), "video_frames", "TOY", "clip1", "img_00001.jpg"))
+    assert tuple(img.shape) == (3, 32, 48) and sz == (64, 48) and -2.2 < img.min() < img.max() < 2.7
+    assert I.normalize(np.array([1.0, 3.0])).tolist() == [0.0, 1.0]
+    u8 = R.postprocess_u8(torch.randn(20, 30), (48, 64))
+    assert u8.dtype == torch.uint8 and int(u8.min()) == 0 and int(u8.max()) == 255
+
+
+@pytest.mark.gpu
+def test_postprocess_kernel(dev):
+    from mspi_amd import engine as E
+    from oracle import restate as R
+    g = torch.Generator().manual_seed(1)
+    maps = torch.randn(3, 224, 224, generator=g) * 2 - 9
+    out = E.postprocess_u8(maps.to(dev), (480, 640)).cpu()
+    for i in range(3):
+        ref = R.postprocess_u8(maps[i], (480, 640))
+        d = (out[i].int() - ref.int()).abs()
+        assert d.max() <= 1 and (d > 0).float().mean() < 0.02      # rounding ties only
+    assert torch.equal(out, E.postprocess_u8(maps.to(dev), (480, 640)).cpu())
+
+
+@pytest.mark.gpu
+def test_clip_loop_end_to_end(dev, tmp_path):
+    """Synthetic dataset directory -> one grey map per frame, equal to oracle model + oracle post-process."""
+    from PIL import Image
+    from mspi_amd import inference as I
+    from mspi_amd import testing as T
+    from oracle import restate as R
+    root = str(tmp_path / "data")
+    _make_dataset(root)
+    res = (64, 96)
+    I.device = dev
+    I._RESOLUTION[:] = list(res)
+    torch.manual_seed(0)
+    model = I.build_model("x3dl", res)
+    T.randomize_(model.cpu(), 0)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).eval()
+    args = types.SimpleNamespace(clip_size=16, dataset="TOY", split=2, path_data=root, save_path=str(tmp_path / "out"),
+                                 use_sound=True, batch=5)
+    I.inference_dataset(model, args)
+    outs = sorted(os.listdir(os.path.join(args.save_path, "clip1")))
+    assert len(outs) == 34 and outs[0] == "img_00001.jpg"
+    # frame 20 (window frames 5..20) against the oracle pipeline
+    frames = [I.torch_transform(os.path.join(root, "video_frames", "TOY", "clip1", "img_%05d.jpg" % (i + 1)))[0] for i in range(4, 20)]
+    clip = torch.stack(frames).permute(1, 0, 2, 3)[None]
+    aud = I.get_audio_feature(os.path.join(root, "video_audio", "TOY", "clip1", "clip1.wav"), 4, "25")[None]
+    cfg = model.cfg
+    with torch.no_grad():
+        ref, _ = R.audio_visual_forward(sd, clip, aud, "x3dl", cfg.MODEL.LATERAL_BOOL, cfg.MODEL.LATERAL_STRIDE)
+    want = R.postprocess_u8(ref[0], (480, 640)).numpy().astype(int)
+    # the file went through a JPEG encode: compare the device output before encoding instead
+    from mspi_amd import engine as E
+    got = E.postprocess_u8(model(clip.to(dev), aud.to(dev))[0], (480, 640))[0].cpu().numpy().astype(int)
+    assert np.abs(got - want).max() <= 2
+    img = np.asarray(Image.open(os.path.join(args.save_path, "clip1", "img_00020.jpg")))
+    assert img.shape == (480, 640) and np.abs(img.astype(int) - want).mean() < 3.0
