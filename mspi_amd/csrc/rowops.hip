@@ -6,49 +6,57 @@
 namespace mspi {
 
 // ------------------------------------------------------------------ LayerNorm
-// One 64-lane wavefront per row; the row stays in registers (<= 12 float4 per lane,
-// C <= 3072) so x is read once.  Two-pass mean/variance like ATen's CPU kernel.
-constexpr int LN_MAXV = 12;
+// LPR lanes per row (16 / 32 / 64, chosen so that narrow rows do not idle most of a wavefront: C = 96 is only 24
+// float4), 64/LPR rows per wavefront, 4 wavefronts per workgroup.  The row stays in registers (VPT float4 per
+// lane), x is read once; two-pass mean / variance like ATen's CPU kernel.  Loads are unconditional (clamped
+// index + select) so they all fly together.
+constexpr int LN_MAXC = 3072;
 
+template <int LPR, int VPT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx, long sNx,
                                                         float* __restrict__ y, long ldy, long sNy,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, long M, int R, int C,
                                                         int act, const float* __restrict__ table) {
+  constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const long n = row / R;
-  const int r = (int)(row - n * R);
+  const int sub = lane % LPR;
+  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  const bool rok = row < M;
+  const long rr = rok ? row : 0;
+  const long n = rr / R;
+  const int r = (int)(rr - n * R);
   const int nv = C >> 2;
   const float* xr = x + n * sNx + (long)r * ldx;
-  float4 v[LN_MAXV];
+  float4 v[VPT];
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
-    const int i = lane + 64 * j;
-    if (i < nv) {
-      v[j] = *reinterpret_cast<const float4*>(xr + i * 4);
-      s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-    }
+  for (int j = 0; j < VPT; ++j) {
+    const int i = sub + LPR * j;
+    const float4 t = *reinterpret_cast<const float4*>(xr + (i < nv ? i : 0) * 4);
+    v[j] = i < nv ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
   }
-  const float mean = wave_sum(s) / (float)C;
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)C;
   float q = 0.f;
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
-    const int i = lane + 64 * j;
-    if (i < nv) {
+  for (int j = 0; j < VPT; ++j) {
+    if (sub + LPR * j < nv) {
       const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
       q += (a * a + b * b) + (c * c + d * d);
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q / (float)C + eps);
   float* yr = y + n * sNy + (long)r * ldy;
   const float* tr = table ? table + (long)r * C : nullptr;
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
-    const int i = lane + 64 * j;
-    if (i < nv) {
+  for (int j = 0; j < VPT; ++j) {
+    const int i = sub + LPR * j;
+    if (rok && i < nv) {
       const float4 g = *reinterpret_cast<const float4*>(gamma + i * 4);
       const float4 b = *reinterpret_cast<const float4*>(beta + i * 4);
       float4 o;
@@ -291,15 +299,26 @@ extern "C" int mspi_layernorm_fwd(const float* x, int64_t ldx, int64_t sNx, floa
                                   int32_t act, const float* table, mspi_stream_t stream) {
   MSPI_REQUIRE(x && y && gamma && beta, "mspi_layernorm_fwd: null argument");
   const int64_t M = (int64_t)N * R;
-  MSPI_REQUIRE(N > 0 && R > 0 && C > 0 && (C & 3) == 0 && C <= LN_MAXV * 256, "mspi_layernorm_fwd: C=%d must be a multiple of 4, <= %d",
-               C, LN_MAXV * 256);
+  MSPI_REQUIRE(N > 0 && R > 0 && C > 0 && (C & 3) == 0 && C <= LN_MAXC, "mspi_layernorm_fwd: C=%d must be a multiple of 4, <= %d",
+               C, LN_MAXC);
   MSPI_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C && (sNx & 3) == 0 && (sNy & 3) == 0,
                "mspi_layernorm_fwd: bad row/sample stride");
   MSPI_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && (!table || aligned16(table)),
                "mspi_layernorm_fwd: pointers must be 16-B aligned");
-  MSPI_REQUIRE((M + 3) / 4 < (1L << 31), "mspi_layernorm_fwd: too many rows");
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
-                     (long)sNx, y, (long)ldy, (long)sNy, gamma, beta, eps, (long)M, R, C, act, table);
+  MSPI_REQUIRE(M < (1L << 31), "mspi_layernorm_fwd: too many rows");
+  const int nv = C / 4;
+  hipStream_t s = (hipStream_t)stream;
+#define MSPI_LN(LPR, VPT)                                                                                             \
+  hipLaunchKernelGGL((layernorm_kernel<LPR, VPT>), dim3((unsigned)((M + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), dim3(256), \
+                     0, s, x, (long)ldx, (long)sNx, y, (long)ldy, (long)sNy, gamma, beta, eps, (long)M, R, C, act, table)
+  if (nv <= 16) MSPI_LN(16, 1);
+  else if (nv <= 32) MSPI_LN(16, 2);
+  else if (nv <= 64) MSPI_LN(16, 4);
+  else if (nv <= 128) MSPI_LN(32, 4);
+  else if (nv <= 256) MSPI_LN(64, 4);
+  else if (nv <= 512) MSPI_LN(64, 8);
+  else MSPI_LN(64, 12);
+#undef MSPI_LN
   return check_launch("mspi_layernorm_fwd");
 }
 
