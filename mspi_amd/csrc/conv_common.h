@@ -1,0 +1,52 @@
+// Shared by the two implicit-GEMM kernels (conv_gemm.hip: everything through LDS, any layout / precision;
+// conv_gemm_ad.hip: the f16x3 fast path with activations loaded straight into MFMA fragments).
+#pragma once
+#include "common.h"
+
+namespace mspi {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+
+// Precision modes.
+//  PREC_F32   : v_mfma_f32_32x32x2_f32 on fp32 operands (exact fp32 fmaf chain).
+//  PREC_F16X3 : fp32-accurate product on the 16x faster f16 matrix pipe.  Every operand is split
+//               x = hi + lo with hi = f16(x), lo = f16(x - hi) (22 significand bits together) and
+//               the product is accumulated in fp32 as hi*hi + hi*lo + lo*hi by three
+//               v_mfma_f32_32x32x16_f16 (the dropped lo*lo term is 2^-22 relative; f16xf16
+//               products are exact in fp32).  Weights are split once at pack time (pre-scaled by a
+//               power of two so their lo part stays a normal f16); activations are split while they
+//               are staged into LDS.
+enum { PREC_F32 = 0, PREC_F16X3 = 1 };
+
+struct ConvArgs {
+  const float* x;
+  const float* w;
+  const float* bias;
+  const float* res;
+  const float* gate;
+  float* y;
+  int N, T, H, W, C;
+  long sN, sT, sH, sW, sC;
+  int kT, kH, kW, strT, strH, strW, padT, padH, padW;
+  int To, Ho, Wo, Cout;
+  long ldy, ldw, ldr;
+  int act;
+  int M, K;
+  int rows_per_sample;
+  int tiles_n, nblocks;
+  float out_scale;  // F16X3: 1 / (power-of-two weight pre-scale), applied to the accumulator
+  int dbg;          // ablation switches for tools/gemm_probe.py (MSPI_CONV_DBG); 0 in production
+};
+
+constexpr int BK = 32;
+
+// XCD-aware, bijective block remap: blocks dealt to one XCD (bid % 8) get consecutive logical ids, so the
+// N-tiles that re-read one A row panel (and the M-tiles that re-read one weight panel) share that XCD's L2.
+__device__ __forceinline__ int xcd_logical_block(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+}  // namespace mspi

@@ -10,46 +10,11 @@
 // BK=32 floats per step through LDS rows padded to 36 floats, so that the ds_read_b128
 // fragment reads (lane (i,h) takes k = 4h..4h+3 of row i: the MFMA K order is permuted
 // identically for A and B, which a dot product does not care about) are conflict-free.
-#include "common.h"
+#include "conv_common.h"
 #include <stdlib.h>
 
 namespace mspi {
 
-typedef float v16f __attribute__((ext_vector_type(16)));
-typedef _Float16 v8h __attribute__((ext_vector_type(8)));
-typedef _Float16 v4h __attribute__((ext_vector_type(4)));
-
-// Precision modes.
-//  PREC_F32   : v_mfma_f32_32x32x2_f32 on fp32 operands (exact fp32 fmaf chain).
-//  PREC_F16X3 : fp32-accurate product on the 16x faster f16 matrix pipe.  Every operand is split
-//               x = hi + lo with hi = f16(x), lo = f16(x - hi) (22 significand bits together) and
-//               the product is accumulated in fp32 as hi*hi + hi*lo + lo*hi by three
-//               v_mfma_f32_32x32x16_f16 (the dropped lo*lo term is 2^-22 relative; f16xf16
-//               products are exact in fp32).  Weights are split once at pack time (pre-scaled by a
-//               power of two so their lo part stays a normal f16); activations are split while they
-//               are staged into LDS.
-enum { PREC_F32 = 0, PREC_F16X3 = 1 };
-
-struct ConvArgs {
-  const float* x;
-  const float* w;
-  const float* bias;
-  const float* res;
-  const float* gate;
-  float* y;
-  int N, T, H, W, C;
-  long sN, sT, sH, sW, sC;
-  int kT, kH, kW, strT, strH, strW, padT, padH, padW;
-  int To, Ho, Wo, Cout;
-  long ldy, ldw, ldr;
-  int act;
-  int M, K;
-  int rows_per_sample;
-  int tiles_n, nblocks;
-  float out_scale;  // F16X3: 1 / (power-of-two weight pre-scale), applied to the accumulator
-};
-
-constexpr int BK = 32;
 constexpr int LDK = 36;  // padded LDS row (floats): 144 B keeps 16-B alignment, kills b128 conflicts
 constexpr int LDH = 40;  // F16X3: padded LDS row (halves): 80 B rows -> 16 distinct 16-B slots per b128 lane group
 
@@ -75,14 +40,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
 
-  // XCD-aware, bijective block remap: blocks dealt to one XCD (bid % 8) get consecutive
-  // logical ids, so the N-tiles that re-read one A row panel share that XCD's L2.
-  int logical;
-  {
-    const int bid = blockIdx.x, nwg = p.nblocks;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
+  const int logical = xcd_logical_block(blockIdx.x, p.nblocks);
   const int tile_n = logical % p.tiles_n;
   const int tile_m = logical / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -261,10 +219,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
       for (int i = 0; i < AR; ++i) {
         v4h hi, lo;
         hi[0] = (_Float16)ra[i].x; hi[1] = (_Float16)ra[i].y; hi[2] = (_Float16)ra[i].z; hi[3] = (_Float16)ra[i].w;
-        lo[0] = (_Float16)(ra[i].x - (float)hi[0]);
-        lo[1] = (_Float16)(ra[i].y - (float)hi[1]);
-        lo[2] = (_Float16)(ra[i].z - (float)hi[2]);
-        lo[3] = (_Float16)(ra[i].w - (float)hi[3]);
+        if (p.dbg & 1) {
+          lo = hi;
+        } else {
+          lo[0] = (_Float16)(ra[i].x - (float)hi[0]);
+          lo[1] = (_Float16)(ra[i].y - (float)hi[1]);
+          lo[2] = (_Float16)(ra[i].z - (float)hi[2]);
+          lo[3] = (_Float16)(ra[i].w - (float)hi[3]);
+        }
         *reinterpret_cast<v4h*>(&Ah[(rbase + RP * i) * LDH + kv * 4]) = hi;
         *reinterpret_cast<v4h*>(&Al[(rbase + RP * i) * LDH + kv * 4]) = lo;
       }
@@ -345,10 +307,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
   __syncthreads();
   for (int it = 0; it < nk; ++it) {
     const int cur = it & 1;
-    compute_half(cur, 0);
-    if (it + 1 < nk) store_tiles(cur ^ 1);
-    if (it + 2 < nk) load_tiles((it + 2) * BK);
-    compute_half(cur, 1);
+    if (!(p.dbg & 8)) compute_half(cur, 0);
+    if (it + 1 < nk && !(p.dbg & 4)) store_tiles(cur ^ 1);
+    if (it + 2 < nk && !(p.dbg & 2)) load_tiles((it + 2) * BK);
+    if (!(p.dbg & 8)) compute_half(cur, 1);
     __syncthreads();
   }
 
@@ -398,6 +360,8 @@ static void launch_cfg(const ConvArgs& a, bool v4, int prec, hipStream_t s) {
 
 using namespace mspi;
 
+namespace mspi { int launch_conv_ad(ConvArgs& a, long Ml, int* cfg, hipStream_t s); }
+
 static thread_local int g_last_cfg = 0;
 extern "C" int mspi_conv_last_config(void) { return g_last_cfg; }
 
@@ -440,6 +404,22 @@ extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float*
   a.ldy = d->ldy; a.ldw = d->ldw; a.ldr = d->ldr; a.act = d->act;
   a.M = (int)Ml; a.K = (int)K; a.rows_per_sample = To * Ho * Wo;
   a.out_scale = d->prec == PREC_F16X3 ? 1.0f / d->w_scale : 1.0f;
+  static const int dbg = getenv("MSPI_CONV_DBG") ? atoi(getenv("MSPI_CONV_DBG")) : 0;
+  a.dbg = dbg;
+
+  // LDS-DMA form (conv_gemm_ad.hip): measured faster than the register-staged kernel on deep implicit GEMMs
+  // (multi-tap convs, K >= 2048: 208 vs 199 TFLOP/s on the 3x3x3 readout conv), slower on the 1x1x1 layers
+  // (its per-stage address block costs more than it saves there) -- tools/gemm_probe.py.
+  static const int dma_mode = getenv("MSPI_CONV_DMA") ? atoi(getenv("MSPI_CONV_DMA")) : 1;   // 0 never, 1 auto, 2 always
+  const bool deep_conv = (long)d->kT * d->kH * d->kW > 1 && K >= 2048 && Ml >= 16384;
+  if (d->prec == PREC_F16X3 && v4 && (dma_mode == 2 || (dma_mode == 1 && deep_conv))) {
+    int cfg = 0;
+    const int rc = launch_conv_ad(a, Ml, &cfg, (hipStream_t)stream);
+    if (rc >= 0) {
+      g_last_cfg = cfg;
+      return rc == 0 ? check_launch("mspi_conv_fwd") : rc;
+    }
+  }
 
   // Tile choice: among the tiles whose grid fills the chip (>= 1.5 workgroups per CU) take the least padded
   // work, weighted by a per-tile efficiency measured with tools/gemm_probe.py; small problems take 64x64.

@@ -1,0 +1,247 @@
+// f16x3 implicit GEMM, LDS-DMA form -- the production GEMM of the f16x3 path.
+//
+// Ablation of the register-staged kernel in conv_gemm.hip (tools/gemm_probe.py + MSPI_CONV_DBG) showed the LDS
+// pipe, not the matrix pipe, at its limit: splitting the activations on the way IN and staging both operands
+// costs 32 KB of ds_write (~80 B/clk) + 64 KB of ds_read per 128x128x32 step, plus ~200 VALU instructions, against
+// 768 MFMA cycles.  This kernel
+//   * moves both tiles HBM/L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA): no VGPR staging, no ds_write, no
+//     VALU; the implicit-GEMM gather is the per-lane SOURCE address, padding taps read a zero page; the LDS image
+//     is kept conflict-free by an XOR swizzle applied on the source side (rule: linear destination, swizzled
+//     source, same swizzle on the read);
+//   * stages the activations as RAW fp32 and splits them into f16 hi/lo AFTER the fragment read, in registers:
+//     a wave owns 32 output rows x all BN columns, so every activation is split exactly once per workgroup;
+//   * K order inside a 32-deep stage is permuted so that lane (i, h) needs A[i][16h .. 16h+15]: MFMA step s takes
+//     k = 16h + 8s .. +7 for both operands (a dot product does not care);
+//   * double buffered: the DMA of stage it+1 flies under the MFMAs of stage it, one barrier per stage.
+#include "conv_common.h"
+#include <stdlib.h>
+
+namespace mspi {
+
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int BN, bool GATE>
+__global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p) {
+  constexpr int BM = 128;
+  constexpr int TN = BN / 32;
+  constexpr int A_BYTES = BM * 32 * 4;          // raw fp32 activations: 128 rows x 32 k
+  constexpr int P_BYTES = BN * 32 * 2;          // one f16 weight plane: BN rows x 32 k
+  constexpr int STAGE = A_BYTES + 2 * P_BYTES;
+  constexpr int HBI = (BN * 4) / 256;           // weight DMA instructions per thread per plane
+  static_assert(HBI >= 1, "BN >= 64");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int logical = xcd_logical_block(blockIdx.x, p.nblocks);
+  const int tile_n = logical % p.tiles_n, tile_m = logical / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int ntaps = p.kT * p.kH * p.kW;
+
+  // ---- activation DMA assignment: instruction j fills LDS chunks (j*4+wave)*64 + lane (16 B each):
+  //      row r_j = (j*4+wave)*8 + lane/8, slot lane%8; the chunk stored in that slot is c = slot ^ ((r>>1)&7),
+  //      which is the same for all four j -> ONE k cursor per thread.
+  long a_off[4];
+  int a_t[4], a_h[4], a_w[4];
+  bool a_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int m = m0 + (j * 4 + wave) * 8 + (lane >> 3);
+    a_ok[j] = m < p.M;
+    if (!a_ok[j]) m = 0;
+    const int wo = m % p.Wo;
+    const int t1 = m / p.Wo;
+    const int ho = t1 % p.Ho;
+    const int t2 = t1 / p.Ho;
+    const int to = t2 % p.To;
+    const int n = t2 / p.To;
+    a_t[j] = to * p.strT - p.padT;
+    a_h[j] = ho * p.strH - p.padH;
+    a_w[j] = wo * p.strW - p.padW;
+    a_off[j] = (long)n * p.sN + (long)a_t[j] * p.sT + (long)a_h[j] * p.sH + (long)a_w[j] * p.sW;
+  }
+  const int a_chunk = (lane & 7) ^ ((((wave * 8 + (lane >> 3)) >> 1)) & 7);
+  int kc = a_chunk * 4, ktap = 0, kdt = 0, kdh = 0, kdw = 0;
+  while (kc >= p.C) {
+    kc -= p.C;
+    ++ktap;
+    if (++kdw == p.kW) { kdw = 0; if (++kdh == p.kH) { kdh = 0; ++kdt; } }
+  }
+  // ---- weight DMA assignment: plane chunks (i*4+wave)*64 + lane: row r = q/4, slot q%4, segment = slot ^ ((r>>2)&3)
+  const _Float16* wh = reinterpret_cast<const _Float16*>(p.w);
+  const long wplane = (long)p.Cout * p.ldw;
+  const int b_seg = (lane & 3) ^ ((lane >> 4) & 3);
+
+  auto issue_stage = [&](int st, int k0) {
+    unsigned char* base = smem + st * STAGE;
+    const bool kin = ktap < ntaps;
+    const long koff = (long)kdt * p.sT + (long)kdh * p.sH + (long)kdw * p.sW + kc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool inb = kin && a_ok[j] && (unsigned)(a_t[j] + kdt) < (unsigned)p.T &&
+                       (unsigned)(a_h[j] + kdh) < (unsigned)p.H && (unsigned)(a_w[j] + kdw) < (unsigned)p.W;
+      const float* src = inb ? p.x + a_off[j] + koff : g_zero16;
+      __builtin_amdgcn_global_load_lds(src, (lds_void*)(base + (j * 4 + wave) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < HBI; ++i) {
+      const int r = (i * 4 + wave) * 16 + (lane >> 2);
+      const int n = n0 + r;
+      const bool ok = n < p.Cout;
+      const _Float16* q = wh + (long)(ok ? n : 0) * p.ldw + k0 + b_seg * 8;
+      const void* s_hi = ok ? (const void*)q : (const void*)g_zero16;
+      const void* s_lo = ok ? (const void*)(q + wplane) : (const void*)g_zero16;
+      __builtin_amdgcn_global_load_lds(s_hi, (lds_void*)(base + A_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(s_lo, (lds_void*)(base + A_BYTES + P_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+    }
+    kc += BK;
+    while (kc >= p.C) {
+      kc -= p.C;
+      ++ktap;
+      if (++kdw == p.kW) { kdw = 0; if (++kdh == p.kH) { kdh = 0; ++kdt; } }
+    }
+  };
+
+  v16f acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // this lane's fragment row and (for the squeeze-excite gate, 1x1x1 convs only) its sample
+  const int frow = wave * 32 + li;
+  const int fsw = (frow >> 1) & 7;
+  int gm = m0 + frow;
+  if (gm >= p.M) gm = p.M - 1;
+  const float* gate_row = p.gate ? p.gate + (long)(gm / p.rows_per_sample) * p.C : nullptr;
+
+  // ---- a 16-deep MFMA step `sub` of stage st covers k = 16*lh + 8*sub .. +7 of the stage.  It is split in three
+  // pieces so that the fragment reads + f16 split of step s+1 can be interleaved with the MFMAs of step s (a wave
+  // issues in order: LDS latency and the cvt/sub chain would otherwise sit exposed in front of every MFMA group).
+  struct Frag {
+    float4 v0, v1, g0, g1;
+    v8h ah, al, bh[TN], bl[TN];
+  };
+  auto frag_read = [&](Frag& f, int st, int sub, int k0) {
+    const unsigned char* base = smem + st * STAGE;
+    const float* As = reinterpret_cast<const float*>(base);
+    const int c0 = 4 * lh + 2 * sub;   // 16-B chunk index of this lane's first 4 floats
+    f.v0 = *reinterpret_cast<const float4*>(&As[frow * 32 + ((c0 ^ fsw) << 2)]);
+    f.v1 = *reinterpret_cast<const float4*>(&As[frow * 32 + (((c0 + 1) ^ fsw) << 2)]);
+    const _Float16* Bh = reinterpret_cast<const _Float16*>(base + A_BYTES);
+    const _Float16* Bl = reinterpret_cast<const _Float16*>(base + A_BYTES + P_BYTES);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int r = j * 32 + li;
+      const int o = r * 32 + ((((2 * lh + sub)) ^ ((r >> 2) & 3)) << 3);
+      f.bh[j] = *reinterpret_cast<const v8h*>(&Bh[o]);
+      f.bl[j] = *reinterpret_cast<const v8h*>(&Bl[o]);
+    }
+    if (GATE) {
+      const int kk = k0 + 16 * lh + 8 * sub;
+      const bool ok = kk < p.C;
+      f.g0 = *reinterpret_cast<const float4*>(gate_row + (ok ? kk : 0));
+      f.g1 = *reinterpret_cast<const float4*>(gate_row + (ok ? kk + 4 : 0));
+    }
+  };
+  auto frag_split = [&](Frag& f) {
+    float a8[8] = {f.v0.x, f.v0.y, f.v0.z, f.v0.w, f.v1.x, f.v1.y, f.v1.z, f.v1.w};
+    if (GATE) {
+      const float g8[8] = {f.g0.x, f.g0.y, f.g0.z, f.g0.w, f.g1.x, f.g1.y, f.g1.z, f.g1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a8[e] = act_apply(a8[e] * g8[e], MSPI_ACT_SWISH);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      f.ah[e] = (_Float16)a8[e];
+      f.al[e] = (_Float16)(a8[e] - (float)f.ah[e]);
+    }
+  };
+  auto frag_mfma = [&](const Frag& f) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.bh[j], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.bl[j], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.bh[j], acc[j], 0, 0, 0);
+    }
+  };
+
+  const int nk = (int)(p.ldw / BK);   // ldw is a multiple of BK; [K, ldw) is zero in w and reads the zero page in A
+  issue_stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  Frag f0, f1;
+  for (int it = 0; it < nk; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < nk) issue_stage(cur ^ 1, (it + 1) * BK);   // DMA of the next stage flies under this stage's MFMAs
+    frag_read(f0, cur, 0, it * BK);
+    frag_split(f0);
+    // sub-step 1's reads + split interleaved with sub-step 0's MFMAs: per MFMA one LDS read and a few VALU
+    frag_read(f1, cur, 1, it * BK);
+    frag_split(f1);
+    frag_mfma(f0);
+#pragma unroll
+    for (int g = 0; g < 3 * TN; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // 5 VALU
+    }
+    frag_mfma(f1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my DMAs have landed ...
+    __syncthreads();                                         // ... and so have everybody else's; stage `cur` is free
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + j * 32 + li;
+    if (col >= p.Cout) continue;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+    const int rb0 = m0 + wave * 32 + 4 * lh;
+    float rv[16];
+    if (p.res) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rb0 + (r & 3) + 8 * (r >> 2);
+        rv[r] = p.res[row < p.M ? (long)row * p.ldr + col : 0];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rb0 + (r & 3) + 8 * (r >> 2);
+      const float v = acc[j][r] * p.out_scale + bv + rv[r];
+      if (row < p.M) p.y[(long)row * p.ldy + col] = act_apply(v, p.act);
+    }
+  }
+}
+
+// returns 0 when launched, -100 when this path does not apply (caller falls back to conv_gemm.hip)
+int launch_conv_ad(ConvArgs& a, long Ml, int* cfg, hipStream_t s) {
+  const long tm = (Ml + 127) / 128;
+  const long t128 = (a.Cout + 127) / 128, t64 = (a.Cout + 63) / 64;
+  // narrower column tile when it pads less (N = 192: 3 x 64 vs 2 x 128) or when the grid would not fill the chip
+  static const int force_bn = getenv("MSPI_CONV_BN") ? atoi(getenv("MSPI_CONV_BN")) : 0;
+  const bool use64 = force_bn ? force_bn == 64 : (t64 * 64 < t128 * 128 || tm * t128 < 384);
+  const int bn = use64 ? 64 : 128;
+  a.tiles_n = (int)(use64 ? t64 : t128);
+  const long nb = tm * a.tiles_n;
+  if (nb >= (1L << 31)) return -100;
+  a.nblocks = (int)nb;
+  *cfg = (128 << 16) | (bn << 4) | (PREC_F16X3 << 1) | 4;   // loader code 4 = LDS-DMA
+  const dim3 g(a.nblocks), b(256);
+  if (a.gate) {
+    if (use64) hipLaunchKernelGGL((conv_gemm_dma_kernel<64, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((conv_gemm_dma_kernel<128, true>), g, b, 0, s, a);
+  } else {
+    if (use64) hipLaunchKernelGGL((conv_gemm_dma_kernel<64, false>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((conv_gemm_dma_kernel<128, false>), g, b, 0, s, a);
+  }
+  return 0;
+}
+
+}  // namespace mspi

@@ -305,7 +305,7 @@ def conv(x, pk, out=None, res=None, gate=None, act=None):
                                 out.ptr, _stream()), "mspi_conv_fwd")
         if Profiler.active is not None:
             c = lib.mspi_conv_last_config()
-            tm.name = "conv_gemm<%d,%d,%s,%s>" % (c >> 16, (c >> 4) & 0xFFF, "s" if c & 1 else "v4",
+            tm.name = "conv_gemm<%d,%d,%s,%s>" % (c >> 16, (c >> 4) & 0xFFF, "ad" if c & 4 else ("s" if c & 1 else "v4"),
                                                   "f16x3" if (c >> 1) & 1 else "f32")
     return out
 
