@@ -197,52 +197,75 @@ struct AugArgs {
   float scale;
 };
 
-__global__ __launch_bounds__(256) void mvit_aug_kernel(const AugArgs p) {
+// (1) copy part, 16-B vectors: qa[.., 0:Dh] = scale*q, ka[.., 0:Dh] = k, one-hot columns of ka, zero tail of both
+__global__ __launch_bounds__(256) void mvit_aug_copy_kernel(const AugArgs p) {
   const int Nq = p.qT * p.qH * p.qW, Nk = p.kT * p.kH * p.kW;
-  const int J = p.kH + p.kW + p.kT;
+  const int J = p.kH + p.kW + p.kT, DV4 = p.DA >> 2, DH4 = p.Dh >> 2;
   const long qrows = (long)p.B * p.heads * Nq, krows = (long)p.B * p.heads * Nk;
-  const long total = (qrows + krows) * p.DA;
+  const long total = (qrows + krows) * DV4;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int col = (int)(idx % p.DA);
-    long row = idx / p.DA;
+    const int c4 = (int)(idx % DV4);
+    long row = idx / DV4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < qrows) {
+      if (c4 >= DH4 && c4 * 4 < p.Dh + J) continue;   // relative-position columns: written by mvit_aug_rel_kernel
       const int tok = (int)(row % Nq);
       const long bh = row / Nq;
-      const int hd = (int)(bh % p.heads);
-      const long b = bh / p.heads;
-      const float* qr = p.q + (b * Nq + tok) * p.ldq + (long)hd * p.Dh;
-      float v = 0.f;
-      if (col < p.Dh) {
-        v = qr[col] * p.scale;
-      } else if (col < p.Dh + J) {
-        const int j = col - p.Dh;
-        const int wq = tok % p.qW, hq = (tok / p.qW) % p.qH, tq = tok / (p.qW * p.qH);
-        const float* tab = j < p.kH ? p.Rh + ((long)hq * p.kH + j) * p.Dh
-                         : j < p.kH + p.kW ? p.Rw + ((long)wq * p.kW + (j - p.kH)) * p.Dh
-                                           : p.Rt + ((long)tq * p.kT + (j - p.kH - p.kW)) * p.Dh;
-        for (int c = 0; c < p.Dh; c += 4) {
-          const float4 a = *reinterpret_cast<const float4*>(qr + c);
-          const float4 t = *reinterpret_cast<const float4*>(tab + c);
-          v = fmaf(a.x, t.x, v); v = fmaf(a.y, t.y, v); v = fmaf(a.z, t.z, v); v = fmaf(a.w, t.w, v);
-        }
+      if (c4 < DH4) {
+        v = *reinterpret_cast<const float4*>(p.q + ((bh / p.heads) * Nq + tok) * p.ldq + (bh % p.heads) * p.Dh + c4 * 4);
+        v.x *= p.scale; v.y *= p.scale; v.z *= p.scale; v.w *= p.scale;
       }
-      p.qa[row * p.DA + col] = v;
+      *reinterpret_cast<float4*>(p.qa + row * p.DA + c4 * 4) = v;
     } else {
       row -= qrows;
       const int tok = (int)(row % Nk);
       const long bh = row / Nk;
-      const int hd = (int)(bh % p.heads);
-      const long b = bh / p.heads;
-      float v = 0.f;
-      if (col < p.Dh) {
-        v = p.k[(b * Nk + tok) * p.ldk + (long)hd * p.Dh + col];
-      } else if (col < p.Dh + J) {
-        const int j = col - p.Dh;
+      if (c4 < DH4) {
+        v = *reinterpret_cast<const float4*>(p.k + ((bh / p.heads) * Nk + tok) * p.ldk + (bh % p.heads) * p.Dh + c4 * 4);
+      } else {
         const int wk = tok % p.kW, hk = (tok / p.kW) % p.kH, tk = tok / (p.kW * p.kH);
-        v = (j == hk || j == p.kH + wk || j == p.kH + p.kW + tk) ? 1.f : 0.f;
+        const int j0 = c4 * 4 - p.Dh, a = hk, b = p.kH + wk, c = p.kH + p.kW + tk;
+        v.x = (j0 == a || j0 == b || j0 == c) ? 1.f : 0.f;
+        v.y = (j0 + 1 == a || j0 + 1 == b || j0 + 1 == c) ? 1.f : 0.f;
+        v.z = (j0 + 2 == a || j0 + 2 == b || j0 + 2 == c) ? 1.f : 0.f;
+        v.w = (j0 + 3 == a || j0 + 3 == b || j0 + 3 == c) ? 1.f : 0.f;
       }
-      p.ka[row * p.DA + col] = v;
+      *reinterpret_cast<float4*>(p.ka + row * p.DA + c4 * 4) = v;
     }
+  }
+}
+
+// (2) the J dot products per query row: a workgroup = 8 rows x 32 lanes; lane j < J computes q_row . table_j
+// (q loads are wave broadcasts, the tables are a few KB and stay in L1).  Also zero-fills up to the next 4-column
+// boundary so that the copy kernel's vectors and these scalars tile the row exactly.
+template <int DH>
+__global__ __launch_bounds__(256) void mvit_aug_rel_kernel(const AugArgs p) {
+  const int Nq = p.qT * p.qH * p.qW;
+  const int J = p.kH + p.kW + p.kT, J4 = (p.Dh + J + 3) / 4 * 4 - p.Dh;
+  const long qrows = (long)p.B * p.heads * Nq;
+  const long row = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int j = threadIdx.x & 31;
+  if (row >= qrows) return;
+  const int tok = (int)(row % Nq);
+  const long bh = row / Nq;
+  const float* qr = p.q + ((bh / p.heads) * Nq + tok) * p.ldq + (bh % p.heads) * p.Dh;
+  const int wq = tok % p.qW, hq = (tok / p.qW) % p.qH, tq = tok / (p.qW * p.qH);
+  for (int jj = j; jj < J4; jj += 32) {
+    float v = 0.f;
+    if (jj < J) {
+      const float* tab = jj < p.kH ? p.Rh + ((long)hq * p.kH + jj) * p.Dh
+                       : jj < p.kH + p.kW ? p.Rw + ((long)wq * p.kW + (jj - p.kH)) * p.Dh
+                                          : p.Rt + ((long)tq * p.kT + (jj - p.kH - p.kW)) * p.Dh;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int c = 0; c < DH; c += 4) {   // DH is a compile-time constant: all 2*DH/4 loads are in flight together
+        const float4 a = *reinterpret_cast<const float4*>(qr + c);
+        const float4 t = *reinterpret_cast<const float4*>(tab + c);
+        a0 = fmaf(a.x, t.x, a0); a1 = fmaf(a.y, t.y, a1); a2 = fmaf(a.z, t.z, a2); a3 = fmaf(a.w, t.w, a3);
+      }
+      v = (a0 + a1) + (a2 + a3);
+    }
+    p.qa[row * p.DA + p.Dh + jj] = v;
   }
 }
 
@@ -263,10 +286,15 @@ extern "C" int mspi_mvit_qk_augment(const MspiMvitAugDesc* d, const float* q, co
   a.B = d->B; a.heads = d->heads; a.Dh = d->Dh; a.DA = d->DA;
   a.qT = d->qT; a.qH = d->qH; a.qW = d->qW; a.kT = d->kT; a.kH = d->kH; a.kW = d->kW;
   a.ldq = d->ldq; a.ldk = d->ldk; a.scale = d->scale;
-  const long total = ((long)d->B * d->heads * (d->qT * d->qH * d->qW + d->kT * d->kH * d->kW)) * d->DA;
+  MSPI_REQUIRE((d->DA & 3) == 0, "mspi_mvit_qk_augment: DA must be a multiple of 4");
+  const long qrows = (long)d->B * d->heads * d->qT * d->qH * d->qW;
+  const long total = (qrows + (long)d->B * d->heads * d->kT * d->kH * d->kW) * (d->DA / 4);
   long g = (total + 255) / 256;
   if (g > 256L * 32) g = 256L * 32;
-  hipLaunchKernelGGL(mvit_aug_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
+  MSPI_REQUIRE((qrows + 7) / 8 < (1L << 31), "mspi_mvit_qk_augment: too many rows");
+  hipLaunchKernelGGL(mvit_aug_copy_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
+  MSPI_REQUIRE(d->Dh == 96, "mspi_mvit_qk_augment: head_dim %d not instantiated (MViTv2 uses 96)", d->Dh);
+  hipLaunchKernelGGL(mvit_aug_rel_kernel<96>, dim3((unsigned)((qrows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("mspi_mvit_qk_augment");
 }
 

@@ -179,10 +179,11 @@ class SA(HipModule):
         c = self.conv_mask[2]
         return self.conv_mask[0].packed(), E.pack_conv(c.weight, c.bias, None, (1, 1, 1), (0, 1, 1), E.ACT_SIGMOID)
 
-    def run(self, x, mask):
-        """In place on x."""
+    def run(self, x, mask, premask=None):
+        """In place on x.  premask: this module's BasicConv3d output if the caller already computed it
+        (the decoder runs the three SA modules' first convs, which share their input, as ONE conv)."""
         p0, p2 = self.pk
-        m = E.conv(mask, p0)
+        m = E.conv(mask, p0) if premask is None else premask
         if self.k != 1:
             m = E.upsample(m, self.k)
         return E.rowgate(x, E.conv(m, p2))
@@ -359,7 +360,11 @@ class _SaliencyBase(HipModule):
 
     def _pack_decoder(self, split=None):
         r = self.readout
+        # sa_0/1/2.conv_mask[0] are three 3x3x3 convs 512->32 over the SAME masks tensor: one conv 512->96
+        sa_w, sa_b = zip(*[E.fold_bn(m.conv_mask[0].conv.weight, None, m.conv_mask[0].bn) for m in (self.sa_0, self.sa_1, self.sa_2)])
+        sa_cat = E.pack_conv(torch.cat(sa_w, 0), torch.cat(sa_b, 0), None, (1, 1, 1), (1, 1, 1), E.ACT_RELU)
         return {
+            "sa_cat": sa_cat,
             "lat": [self._pack_lateral(k, split if k == 3 else None) for k in range(4)],
             "r0": E.pack_conv(r[0].weight, r[0].bias),
             "r1": E.pack_conv(r[1].weight, r[1].bias, r[2], (1, 1, 1), (1, 1, 1), E.ACT_RELU),
@@ -383,12 +388,13 @@ class _SaliencyBase(HipModule):
         s0 = self._lateral(pk, 0, [v1], out=cat.slice(0, 192))
         s1 = self._lateral(pk, 1, [v2])
         s2 = self._lateral(pk, 2, [v3])
-        self.sa_2.run(s2, masks)
+        pm = E.conv(masks, pk["sa_cat"])                      # [B,4,h,w,96] = the three SA pre-masks side by side
+        self.sa_2.run(s2, masks, pm.slice(64, 32))
         E.upsample(s3, 2, dst=s2, accumulate=True)
-        self.sa_1.run(s1, masks)
+        self.sa_1.run(s1, masks, pm.slice(32, 32))
         E.upsample(s2, 2, dst=s1, accumulate=True)
         E.upsample(s3, 4, dst=s1, accumulate=True)
-        self.sa_0.run(s0, masks)
+        self.sa_0.run(s0, masks, pm.slice(0, 32))
         E.upsample(s1, 2, dst=s0, accumulate=True)
         E.upsample(s2, 4, dst=s0, accumulate=True)
         E.upsample(s3, 8, dst=s0, accumulate=True)
