@@ -30,6 +30,7 @@ class ConvDesc(C.Structure):
         ("act", C.c_int32),
         ("prec", C.c_int32),
         ("w_scale", C.c_float),
+        ("tile", C.c_int32),
     ]
 
 

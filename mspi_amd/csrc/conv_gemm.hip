@@ -360,7 +360,7 @@ static void launch_cfg(const ConvArgs& a, bool v4, int prec, hipStream_t s) {
 
 using namespace mspi;
 
-namespace mspi { int launch_conv_ad(ConvArgs& a, long Ml, int* cfg, hipStream_t s); }
+namespace mspi { int launch_conv_ad(ConvArgs& a, long Ml, int force_bn, int* cfg, hipStream_t s); }
 
 static thread_local int g_last_cfg = 0;
 extern "C" int mspi_conv_last_config(void) { return g_last_cfg; }
@@ -412,31 +412,38 @@ extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float*
   // (its per-stage address block costs more than it saves there) -- tools/gemm_probe.py.
   static const int dma_mode = getenv("MSPI_CONV_DMA") ? atoi(getenv("MSPI_CONV_DMA")) : 1;   // 0 never, 1 auto, 2 always
   const bool deep_conv = (long)d->kT * d->kH * d->kW > 1 && K >= 2048 && Ml >= 16384;
-  if (d->prec == PREC_F16X3 && v4 && (dma_mode == 2 || (dma_mode == 1 && deep_conv))) {
+  const bool dma_ok = d->prec == PREC_F16X3 && v4;
+  MSPI_REQUIRE(d->tile >= -1 && d->tile <= 7 && (d->tile < 6 || dma_ok), "mspi_conv_fwd: tile %d not available for this call", d->tile);
+  if (dma_ok && (d->tile >= 6 || (d->tile < 0 && (dma_mode == 2 || (dma_mode == 1 && deep_conv))))) {
     int cfg = 0;
-    const int rc = launch_conv_ad(a, Ml, &cfg, (hipStream_t)stream);
+    const int rc = launch_conv_ad(a, Ml, d->tile == 6 ? 128 : (d->tile == 7 ? 64 : 0), &cfg, (hipStream_t)stream);
     if (rc >= 0) {
       g_last_cfg = cfg;
       return rc == 0 ? check_launch("mspi_conv_fwd") : rc;
     }
   }
 
-  // Tile choice: among the tiles whose grid fills the chip (>= 1.5 workgroups per CU) take the least padded
-  // work, weighted by a per-tile efficiency measured with tools/gemm_probe.py; small problems take 64x64.
-  struct Cfg { int bm, bn; float eff; };
-  static const Cfg cfgs[6] = {{128, 128, 1.00f}, {128, 64, 1.12f}, {128, 32, 1.40f}, {64, 64, 1.25f},
-                              {128, 128, 1.00f}, {256, 128, 1.10f}};
+  // Tile choice.  time ~ rounds x (work of one workgroup): rounds = ceil(blocks / resident slots) -- whole rounds,
+  // because a 588-block grid on 512 slots takes as long as 1024 blocks would (measured: tools/gemm_probe.py) --
+  // and per-workgroup work ~ bm*bn*(K + K0) with K0 standing for the prologue + epilogue.  All tiles sustain about
+  // the same rate on big grids (eff), so the choice is mostly about padding waste and round quantisation.
+  struct Cfg { int bm, bn, slots; float eff; };
+  static const Cfg cfgs[6] = {{128, 128, 512, 1.00f}, {128, 64, 512, 1.06f}, {128, 32, 768, 1.30f}, {64, 64, 1024, 1.25f},
+                              {128, 128, 512, 1.00f}, {256, 128, 256, 1.10f}};
   static const int force = getenv("MSPI_CONV_TILE") ? atoi(getenv("MSPI_CONV_TILE")) : -1;
   int best = 3;
   double best_cost = 1e300;
   for (int i = 0; i < 4; ++i) {
     const long tm = (Ml + cfgs[i].bm - 1) / cfgs[i].bm, tn = (d->Cout + cfgs[i].bn - 1) / cfgs[i].bn;
-    if (tm * tn < 384 && i != 3) continue;
-    const double cost = (double)(tm * cfgs[i].bm) * (double)(tn * cfgs[i].bn) * cfgs[i].eff;
+    const long blocks = tm * tn;
+    double rounds = (double)blocks / cfgs[i].slots;
+    if (rounds < 6.0) rounds = (double)((blocks + cfgs[i].slots - 1) / cfgs[i].slots);
+    const double cost = rounds * cfgs[i].bm * cfgs[i].bn * cfgs[i].eff * ((double)K + 192.0);
     if (cost < best_cost) { best_cost = cost; best = i; }
   }
   if (best == 0 && !getenv("MSPI_CONV_4WAVE")) best = 4;   // 128x128 runs best with 8 waves (32x64 per wave, 4 waves/SIMD)
   if (force >= 0 && force < 6) best = force;
+  if (d->tile >= 0) best = d->tile;
   const int BMs = cfgs[best].bm, BNs = cfgs[best].bn;
   a.tiles_n = (d->Cout + BNs - 1) / BNs;
   const long nb = ((Ml + BMs - 1) / BMs) * a.tiles_n;

@@ -221,11 +221,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p)
 }
 
 // returns 0 when launched, -100 when this path does not apply (caller falls back to conv_gemm.hip)
-int launch_conv_ad(ConvArgs& a, long Ml, int* cfg, hipStream_t s) {
+int launch_conv_ad(ConvArgs& a, long Ml, int force_bn_arg, int* cfg, hipStream_t s) {
   const long tm = (Ml + 127) / 128;
   const long t128 = (a.Cout + 127) / 128, t64 = (a.Cout + 63) / 64;
   // narrower column tile when it pads less (N = 192: 3 x 64 vs 2 x 128) or when the grid would not fill the chip
-  static const int force_bn = getenv("MSPI_CONV_BN") ? atoi(getenv("MSPI_CONV_BN")) : 0;
+  static const int env_bn = getenv("MSPI_CONV_BN") ? atoi(getenv("MSPI_CONV_BN")) : 0;
+  const int force_bn = force_bn_arg ? force_bn_arg : env_bn;
   const bool use64 = force_bn ? force_bn == 64 : (t64 * 64 < t128 * 128 || tm * t128 < 384);
   const int bn = use64 ? 64 : 128;
   a.tiles_n = (int)(use64 ? t64 : t128);

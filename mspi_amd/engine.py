@@ -31,6 +31,37 @@ def rup4(c):
     return (c + 3) // 4 * 4
 
 
+# ----------------------------------------------------------------------------- conv autotuning
+# Like cudnn.benchmark (which the reference switches on, inference.py:189): the first time a conv shape is seen
+# with autotuning enabled, every kernel instantiation that applies is timed on the real tensors and the fastest is
+# remembered.  Off by default (tile -1 = the library's heuristic); bench.py / inference enable it before the
+# hipGraph is captured.  The cache is keyed by the GEMM shape, so it is shared by all layers with that shape.
+AUTOTUNE = {"on": _os.environ.get("MSPI_AUTOTUNE", "0") == "1", "cache": {}, "reps": 3}
+
+
+def autotune(on=True):
+    AUTOTUNE["on"] = bool(on)
+
+
+def _tune_conv(lib, d, args, key, candidates):
+    best, best_t = -1, float("inf")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for tile in candidates:
+        d.tile = tile
+        if lib.mspi_conv_fwd(C.byref(d), *args) != 0:
+            continue
+        e0.record()
+        for _ in range(AUTOTUNE["reps"]):
+            lib.mspi_conv_fwd(C.byref(d), *args)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        if t < best_t:
+            best, best_t = tile, t
+    AUTOTUNE["cache"][key] = best
+    return best
+
+
 # ----------------------------------------------------------------------------- per-launch timing
 class Profiler:
     """Per-launch HIP-event timing of the C-ABI calls, on the stream the kernels are launched on
@@ -299,10 +330,21 @@ def conv(x, pk, out=None, res=None, gate=None, act=None):
                 4.0 * (N * T * H * W * pk.cin + M * pk.cout * (2 if res is not None else 1) + pk.cout * taps * pk.cin),
                 "M=%d K=%d(%dx%d) N=%d s=%s%s%s" % (M, taps * pk.cin, taps, pk.cin, pk.cout, pk.stride,
                                                   " +res" if res is not None else "", " +gate" if gate is not None else ""))
+    args = (xptr, pk.w.data_ptr(), pk.bias.data_ptr() if pk.bias is not None else None,
+            res.ptr if res is not None else None, gate.data_ptr() if gate is not None else None, out.ptr, _stream())
+    d.tile = -1
+    if AUTOTUNE["on"] and not torch.cuda.is_current_stream_capturing():
+        key = (M, taps * pk.cin_s, pk.cout_s, pk.k, pk.stride, pk.prec, d.sC == 1, res is not None, gate is not None)
+        tile = AUTOTUNE["cache"].get(key)
+        if tile is None:
+            cands = [1, 2, 3, 4] + ([6, 7] if (pk.prec == PREC_F16X3 and d.sC == 1 and Cin % 4 == 0) else [])
+            tile = _tune_conv(lib, d, args, key, cands)
+        d.tile = tile
+    elif AUTOTUNE["cache"]:
+        key = (M, taps * pk.cin_s, pk.cout_s, pk.k, pk.stride, pk.prec, d.sC == 1, res is not None, gate is not None)
+        d.tile = AUTOTUNE["cache"].get(key, -1)
     with tm:
-        check(lib.mspi_conv_fwd(C.byref(d), xptr, pk.w.data_ptr(), pk.bias.data_ptr() if pk.bias is not None else None,
-                                res.ptr if res is not None else None, gate.data_ptr() if gate is not None else None,
-                                out.ptr, _stream()), "mspi_conv_fwd")
+        check(lib.mspi_conv_fwd(C.byref(d), *args), "mspi_conv_fwd")
         if Profiler.active is not None:
             c = lib.mspi_conv_last_config()
             tm.name = "conv_gemm<%d,%d,%s,%s>" % (c >> 16, (c >> 4) & 0xFFF, "ad" if c & 4 else ("s" if c & 1 else "v4"),

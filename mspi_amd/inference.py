@@ -217,6 +217,8 @@ def build_model(model_name, resolution, wa=111, weight=None, use_sound=True):
     model = (AudioVisualSaliencyModel if use_sound else VisualSaliencyModel)(cfg=cfg)
     if weight is not None and os.path.exists(weight):
         model.load_state_dict(torch.load(weight, map_location="cpu"), strict=False)
+    from . import engine as E
+    E.autotune(True)       # first forward times the conv kernel instantiations per shape (cudnn.benchmark upstream, :189)
     return model.to(device).eval()
 
 
