@@ -29,8 +29,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p)
   constexpr int A_BYTES = BM * 32 * 4;          // raw fp32 activations: 128 rows x 32 k
   constexpr int P_BYTES = BN * 32 * 2;          // one f16 weight plane: BN rows x 32 k
   constexpr int STAGE = A_BYTES + 2 * P_BYTES;
-  constexpr int HBI = (BN * 4) / 256;           // weight DMA instructions per thread per plane
-  static_assert(HBI >= 1, "BN >= 64");
+  constexpr int HBI = (BN + 63) / 64;           // weight DMA instructions per wave per plane (16 rows each)
+  static_assert(BN % 32 == 0 && BN >= 32 && BN <= 256, "BN: multiple of 32, <= 256");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,14 +87,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p)
     }
 #pragma unroll
     for (int i = 0; i < HBI; ++i) {
-      const int r = (i * 4 + wave) * 16 + (lane >> 2);
-      const int n = n0 + r;
-      const bool ok = n < p.Cout;
-      const _Float16* q = wh + (long)(ok ? n : 0) * p.ldw + k0 + b_seg * 8;
-      const void* s_hi = ok ? (const void*)q : (const void*)g_zero16;
-      const void* s_lo = ok ? (const void*)(q + wplane) : (const void*)g_zero16;
-      __builtin_amdgcn_global_load_lds(s_hi, (lds_void*)(base + A_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(s_lo, (lds_void*)(base + A_BYTES + P_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+      if ((i * 4 + wave) * 16 < BN) {   // wave-uniform: the last group of 16 rows may not exist for this wave
+        const int r = (i * 4 + wave) * 16 + (lane >> 2);
+        const int n = n0 + r;
+        const bool ok = n < p.Cout;
+        const _Float16* q = wh + (long)(ok ? n : 0) * p.ldw + k0 + b_seg * 8;
+        const void* s_hi = ok ? (const void*)q : (const void*)g_zero16;
+        const void* s_lo = ok ? (const void*)(q + wplane) : (const void*)g_zero16;
+        __builtin_amdgcn_global_load_lds(s_hi, (lds_void*)(base + A_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(s_lo, (lds_void*)(base + A_BYTES + P_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+      }
     }
     kc += BK;
     while (kc >= p.C) {
@@ -220,27 +222,40 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p)
   }
 }
 
-// returns 0 when launched, -100 when this path does not apply (caller falls back to conv_gemm.hip)
+// returns 0 when launched, -100 when this path does not apply (caller falls back to conv_gemm.hip).
+// force_bn: 0 = heuristic; else the column tile (a multiple of 32 up to 256; 1 = "all columns in one tile").
+template <int BN>
+static void launch_bn(const ConvArgs& a, hipStream_t s) {
+  const dim3 g(a.nblocks), b(256);
+  if (a.gate) hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, true>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, false>), g, b, 0, s, a);
+}
+
 int launch_conv_ad(ConvArgs& a, long Ml, int force_bn_arg, int* cfg, hipStream_t s) {
   const long tm = (Ml + 127) / 128;
   const long t128 = (a.Cout + 127) / 128, t64 = (a.Cout + 63) / 64;
-  // narrower column tile when it pads less (N = 192: 3 x 64 vs 2 x 128) or when the grid would not fill the chip
   static const int env_bn = getenv("MSPI_CONV_BN") ? atoi(getenv("MSPI_CONV_BN")) : 0;
-  const int force_bn = force_bn_arg ? force_bn_arg : env_bn;
-  const bool use64 = force_bn ? force_bn == 64 : (t64 * 64 < t128 * 128 || tm * t128 < 384);
-  const int bn = use64 ? 64 : 128;
-  a.tiles_n = (int)(use64 ? t64 : t128);
+  int bn = force_bn_arg ? force_bn_arg : env_bn;
+  if (bn == 1) {   // one column tile holding every output channel: the activations are fetched exactly once
+    bn = (a.Cout + 31) / 32 * 32;
+    if (bn > 256) return -100;
+  }
+  if (bn == 0) bn = (t64 * 64 < t128 * 128 || tm * t128 < 384) ? 64 : 128;   // less padding, or a grid that fills the chip
+  a.tiles_n = (int)((a.Cout + bn - 1) / bn);
   const long nb = tm * a.tiles_n;
   if (nb >= (1L << 31)) return -100;
   a.nblocks = (int)nb;
   *cfg = (128 << 16) | (bn << 4) | (PREC_F16X3 << 1) | 4;   // loader code 4 = LDS-DMA
-  const dim3 g(a.nblocks), b(256);
-  if (a.gate) {
-    if (use64) hipLaunchKernelGGL((conv_gemm_dma_kernel<64, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((conv_gemm_dma_kernel<128, true>), g, b, 0, s, a);
-  } else {
-    if (use64) hipLaunchKernelGGL((conv_gemm_dma_kernel<64, false>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((conv_gemm_dma_kernel<128, false>), g, b, 0, s, a);
+  switch (bn) {
+    case 32: launch_bn<32>(a, s); break;
+    case 64: launch_bn<64>(a, s); break;
+    case 96: launch_bn<96>(a, s); break;
+    case 128: launch_bn<128>(a, s); break;
+    case 160: launch_bn<160>(a, s); break;
+    case 192: launch_bn<192>(a, s); break;
+    case 224: launch_bn<224>(a, s); break;
+    case 256: launch_bn<256>(a, s); break;
+    default: return -100;
   }
   return 0;
 }

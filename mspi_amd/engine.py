@@ -286,8 +286,9 @@ def _out_extent(T, H, W, k, s, p):
     return ((T + 2 * p[0] - k[0]) // s[0] + 1, (H + 2 * p[1] - k[1]) // s[1] + 1, (W + 2 * p[2] - k[2]) // s[2] + 1)
 
 
-def conv(x, pk, out=None, res=None, gate=None, act=None):
-    """x: CL, or a raw 5-D [N,C,T,H,W] / 4-D [N,C,H,W] torch tensor with arbitrary strides."""
+def conv(x, pk, out=None, res=None, gate=None, act=None, tile=None):
+    """x: CL, or a raw 5-D [N,C,T,H,W] / 4-D [N,C,H,W] torch tensor with arbitrary strides.
+    tile: force a kernel instantiation (MspiConvDesc.tile); None = autotune cache / library heuristic."""
     lib = _lib.load()
     d = ConvDesc()
     if isinstance(x, CL):
@@ -333,11 +334,15 @@ def conv(x, pk, out=None, res=None, gate=None, act=None):
     args = (xptr, pk.w.data_ptr(), pk.bias.data_ptr() if pk.bias is not None else None,
             res.ptr if res is not None else None, gate.data_ptr() if gate is not None else None, out.ptr, _stream())
     d.tile = -1
-    if AUTOTUNE["on"] and not torch.cuda.is_current_stream_capturing():
+    if tile is not None:
+        d.tile = tile
+    elif AUTOTUNE["on"] and not torch.cuda.is_current_stream_capturing():
         key = (M, taps * pk.cin_s, pk.cout_s, pk.k, pk.stride, pk.prec, d.sC == 1, res is not None, gate is not None)
         tile = AUTOTUNE["cache"].get(key)
         if tile is None:
-            cands = [1, 2, 3, 4] + ([6, 7] if (pk.prec == PREC_F16X3 and d.sC == 1 and Cin % 4 == 0) else [])
+            cands = [1, 2, 3, 4]
+            if pk.prec == PREC_F16X3 and d.sC == 1 and Cin % 4 == 0:
+                cands += [6, 7] + ([8] if pk.cout_s <= 256 else [])
             tile = _tune_conv(lib, d, args, key, cands)
         d.tile = tile
     elif AUTOTUNE["cache"]:

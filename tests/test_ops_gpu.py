@@ -68,6 +68,31 @@ def test_conv(dev, case, act, prec):
         assert torch.isfinite(out.buf).all()
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("shape", [
+    (2, 96, 2, 9, 11, 200, (1, 1, 1), (1, 1, 1), (0, 0, 0)),     # plain GEMM, ragged M, N not a tile multiple
+    (1, 56, 3, 10, 9, 96, (3, 3, 3), (1, 2, 2), (1, 1, 1)),      # strided multi-tap conv, padded channel count
+    (2, 24, 4, 7, 7, 40, (1, 1, 1), (1, 1, 1), (0, 0, 0)),       # K smaller than one stage
+])
+def test_conv_every_kernel_instantiation(dev, tile, shape):
+    """Each tile / loader instantiation the autotuner may pick (register-staged and LDS-DMA kernels) on the same data."""
+    from mspi_amd import engine as E
+    N, Cin, T, H, W, Cout, k, s, p = shape
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(N, Cin, T, H, W, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) / math.sqrt(Cin * k[0] * k[1] * k[2])
+    b = torch.randn(Cout, generator=g)
+    gate = torch.rand(N, E.rup4(Cin), generator=g) if k == (1, 1, 1) else None
+    xa = x if gate is None else x * gate[:, :Cin].view(N, Cin, 1, 1, 1)
+    xa = xa if gate is None else xa * torch.sigmoid(xa)
+    ref = F.conv3d(xa, w, b, s, p)
+    res = torch.randn_like(ref)
+    ref = F.relu(ref + res)
+    pk = E.pack_conv(w, b, None, s, p, E.ACT_RELU, cin_stored=E.rup4(Cin), device=dev, prec=E.PREC_F16X3)
+    out = E.conv(_cl(x, dev), pk, res=_cl(res, dev), gate=None if gate is None else gate.to(dev), tile=tile)
+    _close(out.as_ncdhw(Cout), ref, 2e-5, "conv tile %d %s" % (tile, shape))
+
+
 def test_conv_f16x3_wide_dynamic_range(dev):
     """The split product must stay fp32-accurate for operands spanning many binades (tiny and large
     activations in one row, weights from 1e-4 to 10) -- plain f16 would be off by 1e-3 here."""
