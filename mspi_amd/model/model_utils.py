@@ -298,6 +298,40 @@ class StaticSaliencyModelConvNext(HipModule):
 
 
 # ------------------------------------------------------------------------------- models
+class _Fork:
+    """Fork the current HIP stream into side streams for independent branches and join them on exit.
+    MSPI_STREAMS=0 runs everything on the current stream."""
+    ENABLED = os.environ.get("MSPI_STREAMS", "1") != "0"
+
+    def __init__(self, owner, device):
+        self.main = torch.cuda.current_stream(device)
+        d = owner.__dict__
+        if "_side_streams" not in d or d["_side_streams"][0].device != device:
+            d["_side_streams"] = [torch.cuda.Stream(device) for _ in range(2)]
+        self.side = d["_side_streams"]
+        self.used = []
+
+    def __enter__(self):
+        self.start = torch.cuda.Event()
+        self.start.record(self.main)
+        return self
+
+    def branch(self, i):
+        if not self.ENABLED:
+            return torch.cuda.stream(self.main)
+        s = self.side[i]
+        s.wait_event(self.start)
+        self.used.append(s)
+        return torch.cuda.stream(s)
+
+    def __exit__(self, *exc):
+        for s in self.used:
+            ev = torch.cuda.Event()
+            ev.record(s)
+            self.main.wait_event(ev)
+        return False
+
+
 def _compose_lateral(c0, c1):
     """(s,1,1)/s conv after a 1x1x1 conv, no nonlinearity between: one conv with
     W[co,ci,tap] = sum_m W1[co,m,tap] W0[m,ci],  b[co] = sum_{tap,m} W1[co,m,tap] b0[m]."""
@@ -494,10 +528,17 @@ class AudioVisualSaliencyModel(_SaliencyBase):
         pk = self.pk
         clips = clips.float()
         B, dev = clips.shape[0], clips.device
-        o1, o0 = self.image_encoder.run(clips)
-        masks = self.adapter.run(o1, o0)
-        aud = self.audnet.forward_cl(audios.float())
-        v1, v2, v3, v4 = self.visnet.forward_cl(self._pack_clips(clips))
+        # Three independent branches (image encoder + adapter | audio encoder | motion encoder) on three HIP streams:
+        # the backbones' many small launches (X3D: ~330 kernels of 20-30 us with ragged tails) overlap the image
+        # encoder's large GEMMs instead of each draining the chip alone.  Fork / join by events, so a hipGraph
+        # capture records them as parallel branches.
+        with _Fork(self, dev) as fk:
+            with fk.branch(0):
+                o1, o0 = self.image_encoder.run(clips)
+                masks = self.adapter.run(o1, o0)
+            with fk.branch(1):
+                aud = self.audnet.forward_cl(audios.float())
+            v1, v2, v3, v4 = self.visnet.forward_cl(self._pack_clips(clips))
         x = self.aud_vis_sync_block.run(v4, aud)
         Rv = v4.T * v4.H * v4.W
         vis_fea = x.tokens(0, v4.T, v4.H, v4.W)
@@ -542,7 +583,9 @@ class VisualSaliencyModel(_SaliencyBase):
         self._check_eval()
         pk = self.pk
         clips = clips.float()
-        o1, o0 = self.image_encoder.run(clips)
-        masks = self.adapter.run(o1, o0)
-        v1, v2, v3, v4 = self.visnet.forward_cl(self._pack_clips(clips))
+        with _Fork(self, clips.device) as fk:
+            with fk.branch(0):
+                o1, o0 = self.image_encoder.run(clips)
+                masks = self.adapter.run(o1, o0)
+            v1, v2, v3, v4 = self.visnet.forward_cl(self._pack_clips(clips))
         return self._decode(pk, v1, v2, v3, [v4], masks), 0
