@@ -324,11 +324,21 @@ class _Fork:
         self.used.append(s)
         return torch.cuda.stream(s)
 
-    def __exit__(self, *exc):
-        for s in self.used:
+    def join(self, i):
+        """Make the main stream wait for branch i now (its results are needed before the others finish)."""
+        s = self.side[i]
+        if self.ENABLED and s in self.used:
             ev = torch.cuda.Event()
             ev.record(s)
             self.main.wait_event(ev)
+            self.used.remove(s)
+
+    def __exit__(self, *exc):
+        for s in list(self.used):
+            ev = torch.cuda.Event()
+            ev.record(s)
+            self.main.wait_event(ev)
+        self.used = []
         return False
 
 
@@ -414,15 +424,22 @@ class _SaliencyBase(HipModule):
             y = E.conv(xs[1], pk["lat"][k][1], res=y)
         return getattr(self, "latlayer_%d" % k)[-1].run(y, out=out)
 
-    def _decode(self, pk, v1, v2, v3, v4_parts, masks):
+    def _laterals_012(self, pk, v1, v2, v3):
+        """latlayer_0..2 need only the motion encoder's first three maps: they run while the image branch is still busy.
+        s0 is produced straight into its channel slice of the readout's 768-channel input."""
         B = v1.N
-        s3 = self._lateral(pk, 3, v4_parts)
-        Tq, H0, W0 = s3.T, s3.H * 8, s3.W * 8
-        cat = E.alloc(B, Tq, H0, W0, 4 * 192, v1.buf.device)
+        cat = E.alloc(B, max(1, v1.T // (self.cfg.MODEL.LATERAL_STRIDE[0] if self.cfg.MODEL.LATERAL_BOOL[0] else 1)),
+                      v1.H, v1.W, 4 * 192, v1.buf.device)
         s0 = self._lateral(pk, 0, [v1], out=cat.slice(0, 192))
-        s1 = self._lateral(pk, 1, [v2])
-        s2 = self._lateral(pk, 2, [v3])
-        pm = E.conv(masks, pk["sa_cat"])                      # [B,4,h,w,96] = the three SA pre-masks side by side
+        return cat, s0, self._lateral(pk, 1, [v2]), self._lateral(pk, 2, [v3])
+
+    def _premask(self, pk, masks):
+        """The three SA modules' first convs (same input) as one 512->96 conv."""
+        return E.conv(masks, pk["sa_cat"])
+
+    def _fuse_readout(self, pk, cat, s0, s1, s2, s3, masks, pm):
+        """SA gating, top-down fusion and readout (model/model_utils.py:566-572)."""
+        B = s0.N
         self.sa_2.run(s2, masks, pm.slice(64, 32))
         E.upsample(s3, 2, dst=s2, accumulate=True)
         self.sa_1.run(s1, masks, pm.slice(32, 32))
@@ -536,9 +553,17 @@ class AudioVisualSaliencyModel(_SaliencyBase):
             with fk.branch(0):
                 o1, o0 = self.image_encoder.run(clips)
                 masks = self.adapter.run(o1, o0)
+                pm = self._premask(pk, masks)
             with fk.branch(1):
                 aud = self.audnet.forward_cl(audios.float())
             v1, v2, v3, v4 = self.visnet.forward_cl(self._pack_clips(clips))
+            cat, s0, s1, s2 = self._laterals_012(pk, v1, v2, v3)
+            fk.join(1)
+            s3, loss = self._sync_and_lateral3(pk, v4, aud)
+        return self._fuse_readout(pk, cat, s0, s1, s2, s3, masks, pm), loss
+
+    def _sync_and_lateral3(self, pk, v4, aud):
+        B, dev = v4.N, v4.buf.device
         x = self.aud_vis_sync_block.run(v4, aud)
         Rv = v4.T * v4.H * v4.W
         vis_fea = x.tokens(0, v4.T, v4.H, v4.W)
@@ -552,8 +577,7 @@ class AudioVisualSaliencyModel(_SaliencyBase):
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         E.neg_cosine(vis_pred, aud_emb, loss, 0.5, False)
         E.neg_cosine(aud_pred, vis_emb, loss, 0.5, True)
-        out = self._decode(pk, v1, v2, v3, [v4, vis_fea], masks)
-        return out, loss[0]
+        return self._lateral(pk, 3, [v4, vis_fea]), loss[0]
 
 
 class VisualSaliencyModel(_SaliencyBase):
@@ -587,5 +611,8 @@ class VisualSaliencyModel(_SaliencyBase):
             with fk.branch(0):
                 o1, o0 = self.image_encoder.run(clips)
                 masks = self.adapter.run(o1, o0)
+                pm = self._premask(pk, masks)
             v1, v2, v3, v4 = self.visnet.forward_cl(self._pack_clips(clips))
-        return self._decode(pk, v1, v2, v3, [v4], masks), 0
+            cat, s0, s1, s2 = self._laterals_012(pk, v1, v2, v3)
+            s3 = self._lateral(pk, 3, [v4])
+        return self._fuse_readout(pk, cat, s0, s1, s2, s3, masks, pm), 0
