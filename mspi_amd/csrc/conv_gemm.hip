@@ -413,11 +413,12 @@ extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float*
   static const int dma_mode = getenv("MSPI_CONV_DMA") ? atoi(getenv("MSPI_CONV_DMA")) : 1;   // 0 never, 1 auto, 2 always
   const bool deep_conv = (long)d->kT * d->kH * d->kW > 1 && K >= 2048 && Ml >= 16384;
   const bool dma_ok = d->prec == PREC_F16X3 && v4;
-  MSPI_REQUIRE(d->tile >= -1 && d->tile <= 8 && (d->tile < 6 || dma_ok) && (d->tile != 8 || d->Cout <= 256),
+  MSPI_REQUIRE(d->tile >= -1 && d->tile <= 11 && (d->tile < 6 || dma_ok) && (d->tile != 8 || d->Cout <= 256),
                "mspi_conv_fwd: tile %d not available for this call", d->tile);
   if (dma_ok && (d->tile >= 6 || (d->tile < 0 && (dma_mode == 2 || (dma_mode == 1 && deep_conv))))) {
+    static const int dma_bn[6] = {128, 64, 1, 96, 192, 32};   // tile 6..11 (1 = all columns in one tile)
     int cfg = 0;
-    const int rc = launch_conv_ad(a, Ml, d->tile == 6 ? 128 : (d->tile == 7 ? 64 : (d->tile == 8 ? 1 : 0)), &cfg, (hipStream_t)stream);
+    const int rc = launch_conv_ad(a, Ml, d->tile >= 6 ? dma_bn[d->tile - 6] : 0, &cfg, (hipStream_t)stream);
     if (rc >= 0) {
       g_last_cfg = cfg;
       return rc == 0 ? check_launch("mspi_conv_fwd") : rc;

@@ -22,7 +22,8 @@ __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f}
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int BN, bool GATE>
+// DENSE: 1x1x1, stride 1, no padding -- a plain GEMM on rows; the per-stage source address is base + k, no tap cursor
+template <int BN, bool GATE, bool DENSE>
 __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p) {
   constexpr int BM = 128;
   constexpr int TN = BN / 32;
@@ -31,7 +32,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p)
   constexpr int STAGE = A_BYTES + 2 * P_BYTES;
   constexpr int HBI = (BN + 63) / 64;           // weight DMA instructions per wave per plane (16 rows each)
   static_assert(BN % 32 == 0 && BN >= 32 && BN <= 256, "BN: multiple of 32, <= 256");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  // Ring depth: 3 stages (two K steps of DMA in flight behind a COUNTED vmcnt + raw s_barrier, so the barrier does
+  // not drain the newest stage) where 3 stages still leave two workgroups per CU, else 2 stages.
+  constexpr int NST = 2;   // measured: a 3-deep ring (BN <= 64) loses a resident workgroup to LDS and is 15-25 % slower
+  constexpr int DMA_PER_STAGE = 4 + 2 * HBI;    // upper bound of this thread's DMA instructions per stage
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -76,14 +81,24 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p)
 
   auto issue_stage = [&](int st, int k0) {
     unsigned char* base = smem + st * STAGE;
-    const bool kin = ktap < ntaps;
-    const long koff = (long)kdt * p.sT + (long)kdh * p.sH + (long)kdw * p.sW + kc;
+    if (DENSE) {
+      const int kk = k0 + a_chunk * 4;
+      const bool kin = kk < p.C;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool inb = kin && a_ok[j] && (unsigned)(a_t[j] + kdt) < (unsigned)p.T &&
-                       (unsigned)(a_h[j] + kdh) < (unsigned)p.H && (unsigned)(a_w[j] + kdw) < (unsigned)p.W;
-      const float* src = inb ? p.x + a_off[j] + koff : g_zero16;
-      __builtin_amdgcn_global_load_lds(src, (lds_void*)(base + (j * 4 + wave) * 1024), 16, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        const float* src = (kin && a_ok[j]) ? p.x + a_off[j] + kk : g_zero16;
+        __builtin_amdgcn_global_load_lds(src, (lds_void*)(base + (j * 4 + wave) * 1024), 16, 0, 0);
+      }
+    } else {
+      const bool kin = ktap < ntaps;
+      const long koff = (long)kdt * p.sT + (long)kdh * p.sH + (long)kdw * p.sW + kc;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool inb = kin && a_ok[j] && (unsigned)(a_t[j] + kdt) < (unsigned)p.T &&
+                         (unsigned)(a_h[j] + kdh) < (unsigned)p.H && (unsigned)(a_w[j] + kdw) < (unsigned)p.W;
+        const float* src = inb ? p.x + a_off[j] + koff : g_zero16;
+        __builtin_amdgcn_global_load_lds(src, (lds_void*)(base + (j * 4 + wave) * 1024), 16, 0, 0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < HBI; ++i) {
@@ -98,11 +113,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p)
         __builtin_amdgcn_global_load_lds(s_lo, (lds_void*)(base + A_BYTES + P_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
       }
     }
-    kc += BK;
-    while (kc >= p.C) {
-      kc -= p.C;
-      ++ktap;
-      if (++kdw == p.kW) { kdw = 0; if (++kdh == p.kH) { kdh = 0; ++kdt; } }
+    if (!DENSE) {
+      kc += BK;
+      while (kc >= p.C) {
+        kc -= p.C;
+        ++ktap;
+        if (++kdw == p.kW) { kdw = 0; if (++kdh == p.kH) { kdh = 0; ++kdt; } }
+      }
     }
   };
 
@@ -171,28 +188,72 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p)
   };
 
   const int nk = (int)(p.ldw / BK);   // ldw is a multiple of BK; [K, ldw) is zero in w and reads the zero page in A
-  issue_stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
   Frag f0, f1;
-  for (int it = 0; it < nk; ++it) {
-    const int cur = it & 1;
-    if (it + 1 < nk) issue_stage(cur ^ 1, (it + 1) * BK);   // DMA of the next stage flies under this stage's MFMAs
-    frag_read(f0, cur, 0, it * BK);
-    frag_split(f0);
-    // sub-step 1's reads + split interleaved with sub-step 0's MFMAs: per MFMA one LDS read and a few VALU
-    frag_read(f1, cur, 1, it * BK);
-    frag_split(f1);
-    frag_mfma(f0);
+  if (NST == 2) {
+    issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+      const int cur = it & 1;
+      if (it + 1 < nk) issue_stage(cur ^ 1, (it + 1) * BK);   // DMA of the next stage flies under this stage's MFMAs
+      frag_read(f0, cur, 0, it * BK);
+      frag_split(f0);
+      // sub-step 1's reads + split interleaved with sub-step 0's MFMAs: per MFMA one LDS read and a few VALU
+      frag_read(f1, cur, 1, it * BK);
+      frag_split(f1);
+      frag_mfma(f0);
 #pragma unroll
-    for (int g = 0; g < 3 * TN; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // 5 VALU
+      for (int g = 0; g < 3 * TN; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // 5 VALU
+      }
+      frag_mfma(f1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my DMAs have landed ...
+      __syncthreads();                                         // ... and so have everybody else's; stage `cur` is free
     }
-    frag_mfma(f1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my DMAs have landed ...
-    __syncthreads();                                         // ... and so have everybody else's; stage `cur` is free
+  } else {
+    // 3-deep ring.  Every thread issues the same number of DMA instructions per stage (masked lanes read the zero
+    // page, missing weight groups are wave-uniform skips accounted for below), so "all but the newest stage have
+    // landed" is s_waitcnt vmcnt(<instructions of one stage>).  Raw s_barrier: __syncthreads() would add vmcnt(0).
+    const int my_dma = 4 + 2 * ((wave * 16 < BN ? 1 : 0) + ((4 + wave) * 16 < BN ? 1 : 0) + ((8 + wave) * 16 < BN ? 1 : 0) +
+                                ((12 + wave) * 16 < BN ? 1 : 0));
+    issue_stage(0, 0);
+    if (nk > 1) issue_stage(1, BK);
+    if (nk > 1) {
+      if (my_dma == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int it = 0; it < nk; ++it) {
+      const int nxt2 = cur >= 1 ? cur - 1 : 2;   // (cur + 2) % 3
+      if (it + 2 < nk) issue_stage(nxt2, (it + 2) * BK);
+      frag_read(f0, cur, 0, it * BK);
+      frag_split(f0);
+      frag_read(f1, cur, 1, it * BK);
+      frag_split(f1);
+      frag_mfma(f0);
+#pragma unroll
+      for (int g = 0; g < 3 * TN; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      }
+      frag_mfma(f1);
+      // stage it+1 must have landed before anybody reads it; stage it+2 (just issued) may stay in flight
+      if (it + 2 < nk) {
+        if (my_dma == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur = cur == 2 ? 0 : cur + 1;
+    }
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
@@ -227,8 +288,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p)
 template <int BN>
 static void launch_bn(const ConvArgs& a, hipStream_t s) {
   const dim3 g(a.nblocks), b(256);
-  if (a.gate) hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, true>), g, b, 0, s, a);
-  else hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, false>), g, b, 0, s, a);
+  const bool dense = a.kT * a.kH * a.kW == 1 && a.strT == 1 && a.strH == 1 && a.strW == 1 && a.padT == 0 && a.padH == 0 &&
+                     a.padW == 0;
+  if (a.gate) hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, true, true>), g, b, 0, s, a);   // the gate implies 1x1x1
+  else if (dense) hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, false, true>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, false, false>), g, b, 0, s, a);
 }
 
 int launch_conv_ad(ConvArgs& a, long Ml, int force_bn_arg, int* cfg, hipStream_t s) {

@@ -342,7 +342,7 @@ def conv(x, pk, out=None, res=None, gate=None, act=None, tile=None):
         if tile is None:
             cands = [1, 2, 3, 4]
             if pk.prec == PREC_F16X3 and d.sC == 1 and Cin % 4 == 0:
-                cands += [6, 7] + ([8] if pk.cout_s <= 256 else [])
+                cands += [6, 7, 9, 10] + ([8] if pk.cout_s <= 256 else [])
             tile = _tune_conv(lib, d, args, key, cands)
         d.tile = tile
     elif AUTOTUNE["cache"]:
