@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-autotune", action="store_true", help="keep the library's tile heuristic (default: time the "
                     "kernel instantiations per conv shape during the first, untimed forward -- cudnn.benchmark's role upstream)")
+    ap.add_argument("--tune-cache", default=None, help="JSON file of tile choices: loaded when it exists (no tuning launches, "
+                    "e.g. under rocprofv3), otherwise written after the first forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel timing table to stderr")
@@ -67,6 +69,23 @@ def cpu_baseline(sd, cfg, name, clips, audio, budget_s=25.0):
     return {"value": round(n / el, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "%d single-clip forwards of the same workload (B=1) through oracle/restate.py, torch %s CPU fp32"
                       % (n, torch.__version__)}
+
+
+def pmc_traffic(kname, model, B, S, wa):
+    """HBM bytes per launch of `kname` from the committed rocprofv3 counter passes (profiles/*_traffic.json, written by
+    profiles/summarize.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload; gfx950 corrections
+    applied there).  bench.py cannot collect PMC counters on itself, so this is the last profiled build's figure."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if t.get("workload") == [model, B, S, wa] and kname in t.get("kernels", {}):
+            k = t["kernels"][kname]
+            return {"traffic": round(k["read_bytes"] + k["write_bytes"]), "traffic_unit": "HBM bytes/launch (2*FETCH_SIZE + WRITE_SIZE, KiB->B)",
+                    "traffic_source": "profiles/" + os.path.basename(f)}
+    return {}
 
 
 def main():
@@ -105,9 +124,14 @@ def main():
 
     gathered = [torch.empty(B, S, S, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
 
-    E.autotune(not args.no_autotune)
+    have_cache = bool(args.tune_cache) and os.path.exists(args.tune_cache)
+    if have_cache:
+        E.load_autotune(args.tune_cache)
+    E.autotune(not args.no_autotune and not have_cache)
     out, loss = model(clips, audio)               # packs weights, warms the allocator, autotunes the conv tiles
     E.autotune(False)                             # from here on: cached choices only
+    if args.tune_cache and not have_cache and rank == 0:
+        E.save_autotune(args.tune_cache)
     torch.cuda.synchronize()
     graph = None
     if not args.no_graph:
@@ -174,11 +198,19 @@ def main():
     }
 
     if not args.no_roofline:
-        # per-launch HIP-event timing of every C-ABI call, eager, same inputs, same stream
-        with E.Profiler() as prof:
-            for _ in range(3):
-                model(clips, audio)
-        torch.cuda.synchronize()
+        # per-launch HIP-event timing of every C-ABI call: eager, same inputs, ONE stream (the branch overlap is
+        # switched off here so that each launch is timed alone on the chip, as rocprofv3's kernel trace does)
+        from mspi_amd.model import model_utils as MU
+        fork, MU._Fork.ENABLED = MU._Fork.ENABLED, False
+        try:
+            model(clips, audio)                   # untimed: the allocator's pools for the one-stream schedule
+            torch.cuda.synchronize()
+            with E.Profiler() as prof:
+                for _ in range(3):
+                    model(clips, audio)
+            torch.cuda.synchronize()
+        finally:
+            MU._Fork.ENABLED = fork
         summ = prof.summary()
         tot = sum(d["ms"] for d in summ.values())
         if args.kernel_table:
@@ -205,11 +237,14 @@ def main():
             # algorithmic flop (hi*hi + hi*lo + lo*hi), so the matrix pipe is 3x busier than `frac` says.
             line["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(tflops, 3), "peak": peak,
                                 "unit": "TFLOP/s", "frac": round(tflops / peak, 4), "traffic": None,
+                                "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"]),
                                 "mfma_dtype": "f16 (3 products per fp32 multiply, fp32 accumulate)" if f16x3 else "f32",
                                 "mfma_pipe_frac": round((3 if f16x3 else 1) * tflops / peak, 4)}
         else:
             line["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
+                                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"])}
+        line["roofline"].update(pmc_traffic(kname, name, B, S, args.wa))
         line["roofline"]["launches_per_step"] = d["calls"] // 3
         line["roofline"]["avg_launch_us"] = round(1e3 * d["ms"] / d["calls"], 3)
         line["roofline"]["share_of_step"] = round(d["ms"] / tot, 4)

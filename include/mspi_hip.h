@@ -95,7 +95,8 @@ int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float* w, const f
                   float* y, mspi_stream_t stream);
 
 /* Which kernel instantiation the calling thread's last mspi_conv_fwd launched:
- * (BM << 16) | (BN << 4) | (prec << 1) | loader (0 = 16-B vector gather, 1 = scalar gather).  For profiling. */
+ * (BM << 16) | (BN << 4) | (8 if 8 waves) | (4 if LDS-DMA staging) | (prec << 1) | (1 if scalar gather, 0 if
+ * 16-B vector gather).  For profiling: it names the template instantiation rocprofv3 reports. */
 int mspi_conv_last_config(void);
 
 /* ------------------------------------------------------------------------------------

@@ -452,7 +452,7 @@ extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float*
   MSPI_REQUIRE(nb < (1L << 31), "mspi_conv_fwd: grid too large");
   a.nblocks = (int)nb;
   hipStream_t s = (hipStream_t)stream;
-  g_last_cfg = (BMs << 16) | (BNs << 4) | (d->prec << 1) | (v4 ? 0 : 1);
+  g_last_cfg = (BMs << 16) | (BNs << 4) | (best >= 4 ? 8 : 0) | (d->prec << 1) | (v4 ? 0 : 1);
   switch (best) {
     case 0: launch_cfg<128, 128, 2, 2>(a, v4, d->prec, s); break;
     case 1: launch_cfg<128, 64, 2, 2>(a, v4, d->prec, s); break;

@@ -43,6 +43,23 @@ def autotune(on=True):
     AUTOTUNE["on"] = bool(on)
 
 
+def save_autotune(path):
+    """Write the tile choices made so far (MIOpen's find-db role): {repr(shape key): tile code}."""
+    import json
+    with open(path, "w") as f:
+        json.dump({repr(k): v for k, v in AUTOTUNE["cache"].items()}, f, indent=0, sort_keys=True)
+
+
+def load_autotune(path):
+    """Adopt tile choices saved by save_autotune; shapes not in the file fall back to the library heuristic
+    (or are tuned, when autotune is on).  Returns the number of entries."""
+    import ast
+    import json
+    with open(path) as f:
+        AUTOTUNE["cache"].update({ast.literal_eval(k): int(v) for k, v in json.load(f).items()})
+    return len(AUTOTUNE["cache"])
+
+
 def _tune_conv(lib, d, args, key, candidates):
     best, best_t = -1, float("inf")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -352,7 +369,8 @@ def conv(x, pk, out=None, res=None, gate=None, act=None, tile=None):
         check(lib.mspi_conv_fwd(C.byref(d), *args), "mspi_conv_fwd")
         if Profiler.active is not None:
             c = lib.mspi_conv_last_config()
-            tm.name = "conv_gemm<%d,%d,%s,%s>" % (c >> 16, (c >> 4) & 0xFFF, "ad" if c & 4 else ("s" if c & 1 else "v4"),
+            tm.name = "conv_gemm<%d,%d,%s,%s>" % (c >> 16, (c >> 4) & 0xFFF,
+                                                  "dma" if c & 4 else ("s" if c & 1 else "v4") + ("w8" if c & 8 else ""),
                                                   "f16x3" if (c >> 1) & 1 else "f32")
     return out
 

@@ -18,14 +18,28 @@ def short(name):
     return name.split("(")[0][:70]
 
 
+def profiler_name(k):
+    """rocprofv3 kernel name -> the name bench.py's HIP-event profiler uses (engine.conv)."""
+    import re
+    m = re.match(r"conv_gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", k)
+    if m:
+        bm, bn, wm, wn, loader, prec = map(int, m.groups())
+        return "conv_gemm<%d,%d,%s%s,%s>" % (bm, bn, "s" if loader else "v4", "w8" if wm * wn == 8 else "", "f16x3" if prec else "f32")
+    m = re.match(r"conv_gemm_dma_kernel<(\d+),", k)
+    if m:
+        return "conv_gemm<128,%s,dma,f16x3>" % m.group(1)
+    return None
+
+
 def main(src, tag):
     here = os.path.dirname(os.path.abspath(__file__))
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    trace = "trace_serial" if os.path.isdir(os.path.join(src, "trace_serial")) else "trace"   # MSPI_STREAMS=0: one launch at a time
+    stats = (glob.glob(os.path.join(src, trace, "*_kernel_stats.csv")) + glob.glob(os.path.join(src, trace, "*", "*_kernel_stats.csv")))[0]
     rows = list(csv.DictReader(open(stats)))
     pmc = {}
     for ctr, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         acc = defaultdict(lambda: [0.0, 0])
-        for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+        for f in glob.glob(os.path.join(src, sub, "*_counter_collection.csv")) + glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] == ctr:
                     a = acc[short(r["Kernel_Name"])]
@@ -43,6 +57,20 @@ def main(src, tag):
                 "%.3f" % (2 * fe[0] / fe[1] * 1024 / 1e6) if fe and fe[1] else "",
                 "%.3f" % (wr[0] / wr[1] * 1024 / 1e6) if wr and wr[1] else ""))
     print(open(out).read())
+    # per-launch HBM bytes keyed by bench.py's kernel names (weighted over the template variants that share a name)
+    import json
+    agg = {}
+    for k in set(pmc["FETCH_SIZE"]) | set(pmc["WRITE_SIZE"]):
+        pn = profiler_name(k)
+        if pn is None:
+            continue
+        fe, wr = pmc["FETCH_SIZE"].get(k, [0.0, 0]), pmc["WRITE_SIZE"].get(k, [0.0, 0])
+        a = agg.setdefault(pn, [0.0, 0, 0.0, 0])
+        a[0] += 2 * fe[0] * 1024; a[1] += fe[1]; a[2] += wr[0] * 1024; a[3] += wr[1]
+    wl = json.load(open(os.path.join(src, "workload.json"))) if os.path.exists(os.path.join(src, "workload.json")) else ["x3dl", 8, 224, 300]
+    with open(os.path.join(here, "%s_traffic.json" % tag), "w") as f:
+        json.dump({"workload": wl, "kernels": {k: {"read_bytes": a[0] / max(a[1], 1), "write_bytes": a[2] / max(a[3], 1), "launches": a[1]}
+                                                for k, a in sorted(agg.items())}}, f, indent=1)
 
 
 if __name__ == "__main__":

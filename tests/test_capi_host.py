@@ -165,3 +165,20 @@ def test_state_dict_roots_match_reference_names():
               "image_encoder.encoder.stages_2.blocks.8.mlp.fc2.bias", "audnet.layer4.0.downsample.0.weight"):
         assert k in sd, k
     assert "aud_vis_sync_block.blocks.0.attn.qkv.bias" not in sd and "aud_vis_sync_block.vis_pos_embed" not in sd
+
+
+def test_autotune_cache_roundtrip(tmp_path):
+    """engine.save_autotune / load_autotune: the shape keys (nested tuples) survive the JSON file."""
+    from mspi_amd import engine as E
+    saved = dict(E.AUTOTUNE["cache"])
+    try:
+        E.AUTOTUNE["cache"].clear()
+        key = (25088, 768, 192, (1, 1, 1), (1, 1, 1), E.PREC_F16X3, True, False, False)
+        E.AUTOTUNE["cache"][key] = 7
+        E.save_autotune(str(tmp_path / "t.json"))
+        E.AUTOTUNE["cache"].clear()
+        assert E.load_autotune(str(tmp_path / "t.json")) == 1
+        assert E.AUTOTUNE["cache"] == {key: 7}
+    finally:
+        E.AUTOTUNE["cache"].clear()
+        E.AUTOTUNE["cache"].update(saved)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round profile on the GPU box: bench line, rocprofv3 kernel trace of the same command, HBM counter passes.
+# usage: tools/profile_round.sh <tag>      (writes gpurun_out/prof_<tag>/...)
+set -e
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+CACHE=$OUT/tune_x3dl.json
+rm -f $CACHE
+python3 bench.py --steps 20 --warmup 5 --tune-cache $CACHE > $OUT/bench.json 2> $OUT/bench.err
+echo "bench done"; cat $OUT/bench.json
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o r --output-format csv -- python3 bench.py --steps 20 --warmup 5 --tune-cache $CACHE --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+echo "trace done"
+export MSPI_STREAMS=0
+rocprofv3 --kernel-trace --stats -d $OUT/trace_serial -o r --output-format csv -- python3 bench.py --steps 20 --warmup 5 --tune-cache $CACHE --no-cpu-baseline > $OUT/bench_under_rocprof_serial.json 2> $OUT/trace_serial.err
+echo "serial trace done"
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o r --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-graph --tune-cache $CACHE --no-cpu-baseline --no-roofline > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o r --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-graph --tune-cache $CACHE --no-cpu-baseline --no-roofline > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+echo "write done"
+# keep only the small summaries (the raw traces are tens of MB)
+find $OUT -name "*_kernel_trace.csv" -delete
