@@ -229,6 +229,32 @@ size_t mspi_postprocess_workspace(int32_t N, int32_t H, int32_t W, int32_t Ho, i
 int mspi_postprocess_u8(const float* logmap, unsigned char* out, void* workspace, int32_t N, int32_t H, int32_t W,
                         int32_t Ho, int32_t Wo, mspi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Fused channel MLP on rows:  y = res + W2 . act( W1 . LN(x) + b1 ) + b2,  the 4C-wide hidden
+ * activation stays on the CU (csrc/mlp_fused.hip).  f16x3 split products, fp32 accumulate.
+ * Replaces: timm ConvNeXt block norm -> mlp.fc1 -> GELU -> mlp.fc2 -> gamma -> + shortcut
+ *   (via model/model_utils.py:361,380), and the LN -> Mlp -> residual tail of
+ *   SwinTransformerBlock3D.forward_part2 (backbones/video_swin_transformer.py:262-263) and
+ *   MultiScaleBlock (backbones/MViT.py:1420-1432) when dim_out == dim.
+ * C in {96, 192}; hidden a multiple of 32, <= 1024; x, res, y row-major with strides ldx/ldr/ldy.
+ * w_packed: mspi_mlp_packed_bytes(C, hidden) bytes of f16, per hidden chunk j of 32 units
+ *   W1 part [ks < C/16][hi,lo][lane < 64][e < 8] = W1s[j*32 + lane%32][16 ks + 8 (lane/32) + e]
+ *   W2 part [s < 2][ct < C/32][hi,lo][lane][e]   = W2s[ct*32 + lane%32][j*32 + (2s + e/4)*8 + 4 (lane/32) + e%4]
+ * with W1s = w1_scale * fc1.weight [hidden, C], W2s = w2_scale * (out_scale (.) fc2.weight) [C, hidden],
+ * hi = f16(Ws), lo = f16(Ws - hi)  (engine.pack_mlp builds it). */
+typedef struct {
+  int64_t M;                 /* rows */
+  int32_t C, hidden;
+  int64_t ldx, ldr, ldy;     /* row strides in floats */
+  int32_t ln;                /* 1: LayerNorm over C (gamma, beta, eps) applied to x first */
+  int32_t act;               /* MSPI_ACT_* between the two layers */
+  float eps;
+  float w1_scale, w2_scale;  /* powers of two the packed weights were multiplied by */
+} MspiMlpDesc;
+size_t mspi_mlp_packed_bytes(int32_t C, int32_t hidden);
+int mspi_mlp_fwd(const MspiMlpDesc* d, const void* x, const void* gamma, const void* beta, const void* w_packed,
+                 const void* b1, const void* b2, const void* res, void* y, mspi_stream_t stream);
+
 /* y = a + b over n floats (plain residual add where no producer can fuse it). */
 int mspi_add(const float* a, const float* b, float* y, int64_t n, mspi_stream_t stream);
 

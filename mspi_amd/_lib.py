@@ -67,6 +67,15 @@ class MvitAugDesc(C.Structure):
     ]
 
 
+class MlpDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int64), ("C", C.c_int32), ("hidden", C.c_int32),
+        ("ldx", C.c_int64), ("ldr", C.c_int64), ("ldy", C.c_int64),
+        ("ln", C.c_int32), ("act", C.c_int32), ("eps", C.c_float),
+        ("w1_scale", C.c_float), ("w2_scale", C.c_float),
+    ]
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -91,6 +100,8 @@ _SIGNATURES = {
     "mspi_mean_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mspi_neg_cosine": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P]),
     "mspi_add": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "mspi_mlp_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "mspi_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mspi_postprocess_workspace": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "mspi_postprocess_u8": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
 }

@@ -122,8 +122,7 @@ class MultiScaleBlock(HipModule):
               "pq": dw(a.pool_q), "pk": dw(a.pool_k), "pv": dw(a.pool_v),
               "nq": (_f(a.norm_q.weight), _f(a.norm_q.bias)), "nk": (_f(a.norm_k.weight), _f(a.norm_k.bias)),
               "nv": (_f(a.norm_v.weight), _f(a.norm_v.bias)),
-              "fc1": E.pack_conv(self.mlp.fc1.weight, self.mlp.fc1.bias, act=E.ACT_GELU),
-              "fc2": E.pack_conv(self.mlp.fc2.weight, self.mlp.fc2.bias), "rel": {}}
+              "mlp": E.pack_mlp_tail(self.mlp.fc1, self.mlp.fc2), "rel": {}}
         if hasattr(self, "proj"):
             pk["skip"] = E.pack_conv(self.proj.weight, self.proj.bias)
         return pk
@@ -161,8 +160,7 @@ class MultiScaleBlock(HipModule):
         if self.pool_skip is not None:
             skip = E.maxpool(skip, self.kernel_skip, self.stride_skip, tuple(int(kk // 2) for kk in self.kernel_skip))
         x = E.conv(o, pk["proj"], res=skip)
-        h2 = E.layernorm(x, *pk["n2"], 1e-6)
-        return E.conv(E.conv(h2, pk["fc1"]), pk["fc2"], res=x)
+        return E.mlp_tail(x, pk["mlp"], pk["n2"], 1e-6, res=x)   # dim 96 / 192: one fused launch (mspi_mlp_fwd)
 
 
 class MViT(HipModule):

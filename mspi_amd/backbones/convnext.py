@@ -7,7 +7,9 @@ with timm's FeatureListNet key names (`stem_0, stem_1, stages_{i}.downsample.{0,
 stages_{i}.blocks.{j}.{conv_dw,norm,mlp.fc1,mlp.fc2,gamma}`) -- PARITY UNPINNED.
 
 Per block: dw7x7 (dwconv kernel) -> LayerNorm 1e-6 -> fc1+GELU (GEMM epilogue) -> fc2 with the
-layer-scale gamma folded into its weights and the shortcut add in its epilogue: 4 launches.
+layer-scale gamma folded into its weights and the shortcut add in its epilogue: 4 launches for
+dim >= 384; for dim 96 / 192 everything after the dwconv is ONE launch (mspi_mlp_fwd: the 4C-wide
+hidden activation never leaves the CU).
 """
 import torch
 import torch.nn as nn
@@ -38,13 +40,11 @@ class ConvNeXtBlock(HipModule):
     def _pack(self):
         return {"dw": E.pack_dwconv(self.conv_dw.weight, self.conv_dw.bias, None, (1, 1, 1), (0, 3, 3)),
                 "ln": (self.norm.weight.detach().float().contiguous(), self.norm.bias.detach().float().contiguous()),
-                "fc1": E.pack_conv(self.mlp.fc1.weight, self.mlp.fc1.bias, act=E.ACT_GELU),
-                "fc2": E.pack_conv(self.mlp.fc2.weight, self.mlp.fc2.bias, out_scale=self.gamma)}
+                "mlp": E.pack_mlp_tail(self.mlp.fc1, self.mlp.fc2, out_scale=self.gamma)}   # stages 1-2: ONE launch
 
     def run(self, x):
         pk = self.pk
-        y = E.layernorm(E.dwconv(x, pk["dw"]), pk["ln"][0], pk["ln"][1], 1e-6)
-        return E.conv(E.conv(y, pk["fc1"]), pk["fc2"], res=x)
+        return E.mlp_tail(E.dwconv(x, pk["dw"]), pk["mlp"], pk["ln"], 1e-6, res=x)
 
 
 class ConvNeXtStage(HipModule):

@@ -107,8 +107,7 @@ class SwinTransformerBlock3D(HipModule):
         a, m = self.attn, self.mlp
         return {"n1": (_f(self.norm1.weight), _f(self.norm1.bias)), "n2": (_f(self.norm2.weight), _f(self.norm2.bias)),
                 "qkv": E.pack_conv(a.qkv.weight, a.qkv.bias), "proj": E.pack_conv(a.proj.weight, a.proj.bias),
-                "fc1": E.pack_conv(m.fc1.weight, m.fc1.bias, act=E.ACT_GELU), "fc2": E.pack_conv(m.fc2.weight, m.fc2.bias),
-                "geo": {}}
+                "mlp": E.pack_mlp_tail(m.fc1, m.fc2), "geo": {}}
 
     def _geometry(self, pk, D, H, W):
         """Per input grid: clamped window, token index table, key-major bias and mask (device tensors)."""
@@ -139,8 +138,7 @@ class SwinTransformerBlock3D(HipModule):
         o = E.attention(qkv, x.N * nwin, N, a.num_heads, self.dim // a.num_heads, a.scale, biasT=biasT, maskT=maskT,
                         tok_idx=tok_idx)
         x = E.conv(o, pk["proj"], res=x)
-        h = E.layernorm(x, *pk["n2"], 1e-5)
-        return E.conv(E.conv(h, pk["fc1"]), pk["fc2"], res=x)
+        return E.mlp_tail(x, pk["mlp"], pk["n2"], 1e-5, res=x)   # dim 96 / 192: one fused launch (mspi_mlp_fwd)
 
 
 class PatchMerging(HipModule):

@@ -35,7 +35,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // ~40 instructions per call site and GEMM epilogues have 64 of them.
 __device__ __forceinline__ float fast_erf(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));   // v_rcp_f32 (1 ulp); __frcp_rn expands to a full IEEE division
   float y = fmaf(1.061405429f, t, -1.453152027f);
   y = fmaf(y, t, 1.421413741f);
   y = fmaf(y, t, -0.284496736f);

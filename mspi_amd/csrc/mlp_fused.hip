@@ -1,0 +1,277 @@
+// Fused channel MLP:  y = res + fc2( act( fc1( LayerNorm(x) ) ) )   on rows of a channels-last matrix.
+//
+// The 4C-wide hidden activation of a ConvNeXt / transformer MLP never leaves the CU: for C = 96 the unfused pair
+// (fc1+GELU, fc2+residual) moves 4.2x the bytes of this kernel and both halves are HBM-bound (profiles/r01).
+//
+// Shape of the computation (f16x3 split products on v_mfma_f32_32x32x16_f16, fp32 accumulate -- see conv_gemm.hip):
+//   * a wave owns 32*TM complete rows.  It loads them once, applies the LayerNorm in registers (the two lanes that
+//     share a row exchange partial sums with one DPP/permute), splits them into f16 hi/lo and KEEPS them as MFMA
+//     B-operand fragments for the whole kernel (C/16 * 8 VGPRs per 32 rows).
+//   * the hidden dimension is walked in chunks of 32.  Phase 1 computes the TRANSPOSED chunk
+//         H^T[32 hidden][32 rows] = W1[chunk rows][:] . X^T            (A operand = weights, B operand = X)
+//     so that the accumulator registers of a lane (one row m = lane%32, 16 hidden units) are, after bias + GELU + split,
+//     directly the B operand of phase 2
+//         Y^T[C][32 rows] += W2[:, chunk] . H                          (A operand = weights, B operand = H)
+//     The k-slot -> hidden-unit permutation this implies is absorbed into the (offline) packing of W2.
+//   * weights are packed in exact fragment order (engine.pack_mlp), so a chunk's weights are one linear 24/48 KB
+//     block: staged by LDS-DMA (global_load_lds, 1 KB per wave instruction, no swizzle needed) into a ring of NS
+//     stages, read back with conflict-free ds_read_b128 (lane*16 B).  No activation ever goes through LDS.
+//   * epilogue: Y^T accumulators -> +bias, +residual -> 16-B stores (4 consecutive channels per lane).
+#include "common.h"
+#include <stdlib.h>
+
+namespace mspi {
+
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct MlpArgs {
+  const float* x; const float* gamma; const float* beta; const unsigned char* wp; const float* b1; const float* b2;
+  const float* res; float* y;
+  long M, ldx, ldr, ldy;
+  int nch;            // hidden / 32
+  int ln, act;
+  float eps, inv_s1, inv_s2;
+};
+
+// Packed weight stage (one hidden chunk j of 32 units), all f16, 1 KB = 64 lanes x 8 halves per fragment:
+//   W1 part: [ks = 0..C/16)[plane hi,lo][lane][e]   = W1s[j*32 + lane%32][16*ks + 8*(lane/32) + e]
+//   W2 part: [s = 0..2)[ct = 0..C/32)[plane][lane][e] = W2s[ct*32 + lane%32][j*32 + (2*s + e/4)*8 + 4*(lane/32) + e%4]
+template <int C, int TM, int NS>
+__global__ __launch_bounds__(256, (C == 96 && TM == 1) ? (NS == 2 ? 3 : 2) : 1) void mlp_fused_kernel(const MlpArgs p) {
+  constexpr int KS = C / 16, CT = C / 32;
+  constexpr int W1B = KS * 2048, W2B = 2 * CT * 2048, SB = W1B + W2B;   // bytes per stage
+  constexpr int DPW = SB / 4096;                                        // DMA instructions per wave per stage
+  constexpr int BM = 4 * 32 * TM;
+  static_assert(C % 32 == 0 && SB % 4096 == 0, "C: multiple of 32");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SB + (C == 96 ? 2048 : 4096)];   // the ring, then b1 (hidden <= 1024 floats)
+  float* b1s = reinterpret_cast<float*>(smem + NS * SB);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const long row0 = (long)blockIdx.x * BM + wave * (32 * TM);
+
+  auto issue_stage = [&](int j) {
+    const unsigned char* src = p.wp + (long)j * SB + (wave * DPW) * 1024 + lane * 16;
+    unsigned char* dst = smem + (j % NS) * SB + (wave * DPW) * 1024;
+#pragma unroll
+    for (int d = 0; d < DPW; ++d)
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src + d * 1024), (lds_void*)(dst + d * 1024), 16, 0, 0);
+  };
+
+  // ---- rows: load (clamped), LayerNorm, split.  lane (li, lh) holds row li of each row group, k = 16ks + 8lh + e
+  float xr[TM][KS][8];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    long row = row0 + t * 32 + li;
+    if (row >= p.M) row = p.M - 1;
+    const float* xp = p.x + row * p.ldx + 8 * lh;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 a = *reinterpret_cast<const float4*>(xp + 16 * ks);
+      const float4 b = *reinterpret_cast<const float4*>(xp + 16 * ks + 4);
+      xr[t][ks][0] = a.x; xr[t][ks][1] = a.y; xr[t][ks][2] = a.z; xr[t][ks][3] = a.w;
+      xr[t][ks][4] = b.x; xr[t][ks][5] = b.y; xr[t][ks][6] = b.z; xr[t][ks][7] = b.w;
+    }
+  }
+  // weight ring prologue + bias staging fly under the LayerNorm
+  for (int j = 0; j < NS - 1 && j < p.nch; ++j) issue_stage(j);
+  for (int i = tid; i < p.nch * 32; i += 256) b1s[i] = p.b1[i];
+
+  if (p.ln) {
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      float s = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += xr[t][ks][e];
+      s += __shfl_xor(s, 32, 64);
+      const float mean = s / (float)C;
+      float q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = xr[t][ks][e] - mean; q = fmaf(d, d, q); }
+      q += __shfl_xor(q, 32, 64);
+      const float rstd = rsqrtf(q / (float)C + p.eps);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xr[t][ks][e] = (xr[t][ks][e] - mean) * rstd;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + 16 * ks + 8 * lh);
+      const float4 g1 = *reinterpret_cast<const float4*>(p.gamma + 16 * ks + 8 * lh + 4);
+      const float4 c0 = *reinterpret_cast<const float4*>(p.beta + 16 * ks + 8 * lh);
+      const float4 c1 = *reinterpret_cast<const float4*>(p.beta + 16 * ks + 8 * lh + 4);
+      const float g8[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float c8[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xr[t][ks][e] = fmaf(xr[t][ks][e], g8[e], c8[e]);
+    }
+  }
+  v8h xh[TM][KS], xl[TM][KS];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const _Float16 h = (_Float16)xr[t][ks][e];
+        xh[t][ks][e] = h;
+        xl[t][ks][e] = (_Float16)(xr[t][ks][e] - (float)h);
+      }
+
+  v16f o[TM][CT];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[t][ct][i] = 0.f;
+
+  for (int j = 0; j < p.nch; ++j) {
+    // stage j has landed (mine: counted vmcnt, the newer NS-2 stages may stay in flight; everybody's: barrier);
+    // the barrier also says every wave is done reading stage j-1, whose slot the next DMA overwrites.
+    if (j + NS - 2 < p.nch) {
+      if (NS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if ((NS - 2) * DPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if ((NS - 2) * DPW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if ((NS - 2) * DPW == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+      else if ((NS - 2) * DPW == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (j + NS - 1 < p.nch) issue_stage(j + NS - 1);
+
+    const unsigned char* st = smem + (j % NS) * SB + lane * 16;
+    // ---- phase 1: H^T chunk
+    v16f h[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) h[t][i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const v8h wh = *reinterpret_cast<const v8h*>(st + (ks * 2 + 0) * 1024);
+      const v8h wl = *reinterpret_cast<const v8h*>(st + (ks * 2 + 1) * 1024);
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        h[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[t][ks], h[t], 0, 0, 0);
+        h[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[t][ks], h[t], 0, 0, 0);
+        h[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[t][ks], h[t], 0, 0, 0);
+      }
+    }
+    // ---- bias + activation + split: acc index i <-> hidden unit (i/4)*8 + 4*lh + i%4 of the chunk
+    float bv[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b = *reinterpret_cast<const float4*>(b1s + j * 32 + q * 8 + 4 * lh);
+      bv[q * 4 + 0] = b.x; bv[q * 4 + 1] = b.y; bv[q * 4 + 2] = b.z; bv[q * 4 + 3] = b.w;
+    }
+    v8h hh[TM][2], hl[TM][2];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float u = fmaf(h[t][i], p.inv_s1, bv[i]);
+        const float v = 0.5f * u * (1.f + fast_erf(u * 0.70710678118654752440f));   // nn.GELU (erf form)
+        const _Float16 f = (_Float16)v;
+        hh[t][i >> 3][i & 7] = f;
+        hl[t][i >> 3][i & 7] = (_Float16)(v - (float)f);
+      }
+    // ---- phase 2: Y^T += W2[:, chunk] . H
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const v8h wh = *reinterpret_cast<const v8h*>(st + W1B + ((s * CT + ct) * 2 + 0) * 1024);
+        const v8h wl = *reinterpret_cast<const v8h*>(st + W1B + ((s * CT + ct) * 2 + 1) * 1024);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          o[t][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hh[t][s], o[t][ct], 0, 0, 0);
+          o[t][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hl[t][s], o[t][ct], 0, 0, 0);
+          o[t][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hh[t][s], o[t][ct], 0, 0, 0);
+        }
+      }
+  }
+
+  // ---- epilogue: lane (li, lh) holds, for row li, channels ct*32 + q*8 + 4*lh + 0..3
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const long row = row0 + t * 32 + li;
+    const bool ok = row < p.M;
+    const long rr = ok ? row : 0;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      float4 rv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = ct * 32 + q * 8 + 4 * lh;
+        rv[q] = p.res ? *reinterpret_cast<const float4*>(p.res + rr * p.ldr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = ct * 32 + q * 8 + 4 * lh;
+        const float4 b = *reinterpret_cast<const float4*>(p.b2 + c);
+        float4 v;
+        v.x = fmaf(o[t][ct][q * 4 + 0], p.inv_s2, b.x) + rv[q].x;
+        v.y = fmaf(o[t][ct][q * 4 + 1], p.inv_s2, b.y) + rv[q].y;
+        v.z = fmaf(o[t][ct][q * 4 + 2], p.inv_s2, b.z) + rv[q].z;
+        v.w = fmaf(o[t][ct][q * 4 + 3], p.inv_s2, b.w) + rv[q].w;
+        if (ok) *reinterpret_cast<float4*>(p.y + row * p.ldy + c) = v;
+      }
+    }
+  }
+}
+
+template <int C, int TM, int NS>
+static int launch_mlp(const MlpArgs& a, hipStream_t s) {
+  constexpr int BM = 128 * TM;
+  const long nb = (a.M + BM - 1) / BM;
+  hipLaunchKernelGGL((mlp_fused_kernel<C, TM, NS>), dim3((unsigned)nb), dim3(256), 0, s, a);
+  return 0;
+}
+
+}  // namespace mspi
+
+using namespace mspi;
+
+extern "C" size_t mspi_mlp_packed_bytes(int C, int hidden) {
+  return (size_t)(hidden / 32) * ((size_t)(C / 16) * 2048 + 2 * (size_t)(C / 32) * 2048);
+}
+
+extern "C" int mspi_mlp_fwd(const MspiMlpDesc* d, const void* x, const void* gamma, const void* beta, const void* w_packed,
+                            const void* b1, const void* b2, const void* res, void* y, void* stream) {
+  MSPI_REQUIRE(d && x && w_packed && b1 && b2 && y, "mspi_mlp_fwd: null argument");
+  MSPI_REQUIRE(d->C == 96 || d->C == 192, "mspi_mlp_fwd: C = %d not supported (96, 192)", d->C);
+  MSPI_REQUIRE(d->hidden % 32 == 0 && d->hidden >= 32 && d->hidden <= 1024, "mspi_mlp_fwd: hidden = %d", d->hidden);
+  MSPI_REQUIRE(d->M >= 1 && d->M < (1L << 31), "mspi_mlp_fwd: M = %ld", (long)d->M);
+  MSPI_REQUIRE(d->ldx >= d->C && d->ldy >= d->C && d->ldx % 4 == 0 && d->ldy % 4 == 0 && (!res || (d->ldr >= d->C && d->ldr % 4 == 0)),
+               "mspi_mlp_fwd: row strides must be >= C and multiples of 4 floats");
+  MSPI_REQUIRE(d->act == MSPI_ACT_GELU, "mspi_mlp_fwd: only MSPI_ACT_GELU between the layers (act = %d)", d->act);
+  MSPI_REQUIRE(!d->ln || (gamma && beta), "mspi_mlp_fwd: LayerNorm needs gamma and beta");
+  MSPI_REQUIRE(d->w1_scale > 0.f && d->w2_scale > 0.f, "mspi_mlp_fwd: weight scales must be positive");
+  MlpArgs a;
+  a.x = (const float*)x; a.gamma = (const float*)gamma; a.beta = (const float*)beta; a.wp = (const unsigned char*)w_packed;
+  a.b1 = (const float*)b1; a.b2 = (const float*)b2; a.res = (const float*)res; a.y = (float*)y;
+  a.M = d->M; a.ldx = d->ldx; a.ldr = d->ldr; a.ldy = d->ldy;
+  a.nch = d->hidden / 32; a.ln = d->ln; a.act = d->act; a.eps = d->eps;
+  a.inv_s1 = 1.0f / d->w1_scale; a.inv_s2 = 1.0f / d->w2_scale;
+  static const int variant = getenv("MSPI_MLP_TM") ? atoi(getenv("MSPI_MLP_TM")) : 0;
+  int rc;
+  MSPI_REQUIRE(d->C != 96 || d->hidden <= 512, "mspi_mlp_fwd: hidden = %d > 512 with C = 96", d->hidden);
+  if (d->C == 96) rc = (variant == 2) ? launch_mlp<96, 2, 4>(a, (hipStream_t)stream) :
+                       (variant == 3) ? launch_mlp<96, 1, 2>(a, (hipStream_t)stream) : launch_mlp<96, 1, 3>(a, (hipStream_t)stream);
+  else rc = launch_mlp<192, 1, 3>(a, (hipStream_t)stream);
+  (void)rc;
+  return check_launch("mspi_mlp_fwd");
+}

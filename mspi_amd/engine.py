@@ -268,6 +268,59 @@ def pack_conv(weight, bias=None, bn=None, stride=(1, 1, 1), pad=(0, 0, 0), act=A
     return p
 
 
+class PackedMlp:
+    __slots__ = ("w", "b1", "b2", "c", "hidden", "s1", "s2", "act")
+
+
+def _f16_scale(w):
+    mx = float(w.abs().max())
+    if not math.isfinite(mx):
+        raise MspiError("pack: non-finite weights")
+    e = 0 if mx == 0.0 else max(-10, min(24, int(math.floor(math.log2(16384.0 / mx)))))
+    return float(2.0 ** e)
+
+
+def mlp_supported(c, hidden):
+    """Shapes mspi_mlp_fwd covers (the rows stay in registers as MFMA fragments: C <= 192)."""
+    return DEFAULT_PREC == PREC_F16X3 and c in (96, 192) and hidden % 32 == 0 and hidden <= 1024
+
+
+def pack_mlp(fc1_w, fc1_b, fc2_w, fc2_b, out_scale=None, act=ACT_GELU, device=None):
+    """Fragment-order f16 hi/lo packing of a Linear(C, hidden) -> act -> Linear(hidden, C) pair for mspi_mlp_fwd
+    (layout: include/mspi_hip.h).  out_scale (ConvNeXt layer-scale gamma) is folded into the second layer."""
+    w1 = fc1_w.detach().float().cpu()
+    w2 = fc2_w.detach().float().cpu()
+    b2 = fc2_b.detach().float().cpu()
+    if out_scale is not None:
+        g = out_scale.detach().float().cpu().view(-1)
+        w2, b2 = w2 * g[:, None], b2 * g
+    hidden, c = w1.shape
+    if w2.shape != (c, hidden) or c % 32 or hidden % 32:
+        raise MspiError("pack_mlp: shapes %s / %s" % (tuple(w1.shape), tuple(w2.shape)))
+    nch, ks, ct = hidden // 32, c // 16, c // 32
+    p = PackedMlp()
+    p.s1, p.s2 = _f16_scale(w1), _f16_scale(w2)
+
+    def planes(w, s):
+        ws = w * s
+        hi = ws.to(torch.float16)
+        return hi, (ws - hi.float()).to(torch.float16)
+
+    parts1, parts2 = [], []
+    for pl in planes(w1, p.s1):   # [hidden, C] -> [nch, n32, ks, g2, e8] -> [nch, ks, (g, n) = lane, e]
+        parts1.append(pl.view(nch, 32, ks, 2, 8).permute(0, 2, 3, 1, 4).reshape(nch, ks, 64, 8))
+    for pl in planes(w2, p.s2):   # [C, hidden] -> [ct, c32, nch, s2, eh2, g2, r4] -> [nch, s, ct, (g, c) = lane, (eh, r) = e]
+        parts2.append(pl.view(ct, 32, nch, 2, 2, 2, 4).permute(2, 3, 0, 5, 1, 4, 6).reshape(nch, 2, ct, 64, 8))
+    w1p = torch.stack(parts1, 2).reshape(nch, -1)      # [nch, ks, plane, 64, 8]
+    w2p = torch.stack(parts2, 3).reshape(nch, -1)      # [nch, s, ct, plane, 64, 8]
+    dev = fc1_w.device if device is None else device
+    p.w = torch.cat([w1p, w2p], 1).contiguous().to(dev)
+    p.b1 = fc1_b.detach().float().contiguous().to(dev)
+    p.b2 = b2.contiguous().to(dev)
+    p.c, p.hidden, p.act = c, hidden, act
+    return p
+
+
 class PackedDw:
     __slots__ = ("w", "bias", "k", "stride", "pad", "c", "c_s", "act")
 
@@ -481,6 +534,44 @@ def attention(qkv, B, Ntok, heads, hd, scale, out=None, biasT=None, maskT=None, 
                                 maskT.data_ptr() if maskT is not None else None,
                                 tok_idx.data_ptr() if tok_idx is not None else None, out.ptr, _stream()), "mspi_attn_fwd")
     return out
+
+
+def mlp(x, pk, res=None, ln=None, eps=1e-6, out=None):
+    """out = res + fc2(act(fc1(LN(x)))) in one launch (mspi_mlp_fwd); ln = (gamma, beta) or None."""
+    lib = _lib.load()
+    _need_gpu(x.buf)
+    if x.C != pk.c or not x.dense:
+        raise MspiError("mlp: input has %d channels (dense=%s), packed for %d" % (x.C, x.dense, pk.c))
+    if out is None:
+        out = alloc(x.N, x.T, x.H, x.W, pk.c, x.buf.device)
+    if res is not None and (res.M != x.M or not res.dense):
+        raise MspiError("mlp: residual rows %d != rows %d (or residual not dense)" % (res.M, x.M))
+    d = _lib.MlpDesc()
+    d.M, d.C, d.hidden = x.M, pk.c, pk.hidden
+    d.ldx, d.ldy, d.ldr = x.ld, out.ld, (res.ld if res is not None else 0)
+    d.ln, d.act, d.eps = (1 if ln is not None else 0), pk.act, eps
+    d.w1_scale, d.w2_scale = pk.s1, pk.s2
+    with _Timed("mlp_fused", 4.0 * x.M * pk.c * pk.hidden, 4.0 * x.M * pk.c * (3 if res is not None else 2),
+                "M=%d C=%d hidden=%d" % (x.M, pk.c, pk.hidden)):
+        check(lib.mspi_mlp_fwd(C.byref(d), x.ptr, ln[0].data_ptr() if ln is not None else None,
+                               ln[1].data_ptr() if ln is not None else None, pk.w.data_ptr(), pk.b1.data_ptr(),
+                               pk.b2.data_ptr(), res.ptr if res is not None else None, out.ptr, _stream()), "mspi_mlp_fwd")
+    return out
+
+
+def pack_mlp_tail(fc1, fc2, out_scale=None):
+    """LN -> Linear -> GELU -> Linear (+ residual) tail of a ConvNeXt / Swin / MViT block: the fused kernel where it
+    applies (C in {96, 192}, f16x3), else the two GEMM packs.  Use with mlp_tail()."""
+    if mlp_supported(fc1.in_features, fc1.out_features) and fc2.out_features == fc1.in_features:
+        return ("fused", pack_mlp(fc1.weight, fc1.bias, fc2.weight, fc2.bias, out_scale=out_scale))
+    return ("split", pack_conv(fc1.weight, fc1.bias, act=ACT_GELU), pack_conv(fc2.weight, fc2.bias, out_scale=out_scale))
+
+
+def mlp_tail(x, packed, ln, eps, res):
+    """res + fc2(GELU(fc1(LayerNorm(x)))) with packed = pack_mlp_tail(...), ln = (gamma, beta)."""
+    if packed[0] == "fused":
+        return mlp(x, packed[1], res=res, ln=ln, eps=eps)
+    return conv(conv(layernorm(x, ln[0], ln[1], eps), packed[1]), packed[2], res=res)
 
 
 def space_to_depth(x, out=None):

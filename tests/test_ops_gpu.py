@@ -364,3 +364,34 @@ def test_errors_are_loud(dev):
         E.conv(x, pk)                       # channel mismatch
     with pytest.raises(MspiError):
         E.conv(torch.zeros(1, 12, 1, 4, 4), pk)   # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("C,M,ln,res", [(96, 1000, True, True), (96, 128, False, True), (96, 33, True, False),
+                                        (192, 777, True, True), (192, 256, False, False)])
+def test_mlp_fused(dev, C, M, ln, res):
+    """mspi_mlp_fwd: y = res + fc2(GELU(fc1(LN(x)))) in one launch (ConvNeXt / Swin / MViT MLP tail), ragged M,
+    layer-scale folded into fc2; reference in float64 on the CPU."""
+    from mspi_amd import engine as E
+    if not E.mlp_supported(C, 4 * C):
+        pytest.skip("fused MLP is an f16x3 kernel")
+    g = torch.Generator().manual_seed(C + M)
+    x = torch.randn(M, C, generator=g) * 2 + 0.5
+    r = torch.randn(M, C, generator=g)
+    w1, b1 = torch.randn(4 * C, C, generator=g) * 0.1, torch.randn(4 * C, generator=g) * 0.1
+    w2, b2 = torch.randn(C, 4 * C, generator=g) * 0.05, torch.randn(C, generator=g) * 0.1
+    gm, bt, ls = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g)
+    xd = F.layer_norm(x.double(), (C,), gm.double(), bt.double(), 1e-6) if ln else x.double()
+    ref = (F.gelu(xd @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()) * ls.double()
+    if res:
+        ref = ref + r.double()
+    pk = E.pack_mlp(w1, b1, w2, b2, out_scale=ls, device=dev)
+    xc = E.CL(x.to(dev).view(-1), 0, 1, M, 1, 1, C, C)
+    rc = E.CL(r.to(dev).view(-1), 0, 1, M, 1, 1, C, C) if res else None
+    out = E.mlp(xc, pk, res=rc, ln=(gm.to(dev), bt.to(dev)) if ln else None, eps=1e-6)
+    _close(out.as_rows(), ref.float(), 2e-5, "fused mlp")
+    # same thing through the unfused kernels (LN, fc1+GELU, fc2+res): the two paths agree to fp32 rounding
+    y = E.layernorm(xc, gm.to(dev), bt.to(dev), 1e-6) if ln else xc
+    fc1 = E.pack_conv(w1, b1, act=E.ACT_GELU, device=dev)
+    fc2 = E.pack_conv(w2, b2, out_scale=ls, device=dev)
+    out2 = E.conv(E.conv(y, fc1), fc2, res=rc)
+    _close(out.as_rows(), out2.as_rows().cpu(), 2e-5, "fused vs unfused")
