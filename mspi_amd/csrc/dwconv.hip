@@ -7,6 +7,7 @@
 // generic one (any kernel/stride; also max-pool).  Both remap blocks so that neighbouring outputs
 // share an XCD's L2.
 #include "common.h"
+#include <stdlib.h>
 
 namespace mspi {
 
@@ -120,30 +121,45 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(const DwArgs p) {
 #pragma unroll
     for (int o = 0; o < SW; ++o) acc[o] = bv;
     constexpr int NIN = (SW - 1) * SWS + KW;
+    // kH == KW (square kernels only reach this kernel).  The KW input rows of one dt are fetched as ONE batch of
+    // unconditional loads (clamped address + select): on the small X3D maps the whole grid is a single round of
+    // blocks, so the kernel's length is (number of dependent load phases) x (loaded latency) -- 3 phases, not 9.
     for (int dt = 0; dt < p.kT; ++dt) {
       const int t = t0 + dt;
       if ((unsigned)t >= (unsigned)p.T) continue;
-      for (int dh = 0; dh < p.kH; ++dh) {
-        const int h = h0 + dh;
-        if ((unsigned)h >= (unsigned)p.H) continue;
-        const float* xr = xb + ((long)(t * p.H + h) * p.W) * p.ldx;
-        const float* wr = p.w + (long)((dt * p.kH + dh) * KW) * p.C + cv * 4;
-        float4 wt[KW];
+      constexpr int RB = KW == 3 ? 3 : 1;   // rows per load batch (7x7: 1 and a ROLLED loop -- unrolled, the compiler hoists
+                                            // all 70 input vectors, spills, and the 14x14 maps run 4x slower)
+#pragma unroll 1
+      for (int dh0 = 0; dh0 < KW; dh0 += RB) {
+        float4 xin[RB][NIN];
 #pragma unroll
-        for (int k = 0; k < KW; ++k) wt[k] = *reinterpret_cast<const float4*>(wr + (long)k * p.C);
+        for (int b = 0; b < RB; ++b) {
+          if (dh0 + b >= KW) continue;
+          const int h = h0 + dh0 + b;
+          const bool hv = (unsigned)h < (unsigned)p.H;
+          const float* xr = xb + ((long)(t * p.H + (hv ? h : 0)) * p.W) * p.ldx;
 #pragma unroll
-        for (int j = 0; j < NIN; ++j) {
-          const int w = w0 + j;
-          float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-          if ((unsigned)w < (unsigned)p.W) xv = *reinterpret_cast<const float4*>(xr + (long)w * p.ldx);
+          for (int j = 0; j < NIN; ++j) {
+            const int w = w0 + j;
+            const bool ok = hv && (unsigned)w < (unsigned)p.W;
+            const float4 v = *reinterpret_cast<const float4*>(xr + (long)(ok ? w : 0) * p.ldx);
+            xin[b][j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
 #pragma unroll
-          for (int o = 0; o < SW; ++o) {
-            const int k = j - o * SWS;
-            if (k >= 0 && k < KW) {
-              acc[o].x = fmaf(xv.x, wt[k].x, acc[o].x);
-              acc[o].y = fmaf(xv.y, wt[k].y, acc[o].y);
-              acc[o].z = fmaf(xv.z, wt[k].z, acc[o].z);
-              acc[o].w = fmaf(xv.w, wt[k].w, acc[o].w);
+        for (int b = 0; b < RB; ++b) {
+          if (dh0 + b >= KW) continue;
+          const float* wr = p.w + (long)((dt * KW + dh0 + b) * KW) * p.C + cv * 4;
+#pragma unroll
+          for (int k = 0; k < KW; ++k) {
+            const float4 wv = *reinterpret_cast<const float4*>(wr + (long)k * p.C);
+#pragma unroll
+            for (int o = 0; o < SW; ++o) {
+              const float4 xv = xin[b][o * SWS + k];
+              acc[o].x = fmaf(xv.x, wv.x, acc[o].x);
+              acc[o].y = fmaf(xv.y, wv.y, acc[o].y);
+              acc[o].z = fmaf(xv.z, wv.z, acc[o].z);
+              acc[o].w = fmaf(xv.w, wv.w, acc[o].w);
             }
           }
         }
@@ -171,6 +187,135 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(const DwArgs p) {
       *reinterpret_cast<float4*>(p.pool + ((long)n * nblk + lb) * p.C + cvr * 4) = s;
     }
   }
+}
+
+// Tile kernel: one thread = SH x SW outputs (rows x columns) of one channel-vec4.  Why: the strip kernel issues
+// (NIN + KW) 16-B global loads per input row for SW*KW FMA-vec4 -- 17.5 loads per output for 7x7, 20 for 3x3x3 --
+// and runs at the L1/TA rate (1.6-2.5 TB/s algorithmic, profiles/r01), not at HBM's.  Here
+//   * an input row is loaded once and feeds up to SH output rows (7x7, SH=2, SW=7: 7.4 loads per output),
+//   * the weights come from LDS (staged once per block for the block's <= 32 channel-vec4s), not from L1,
+//   * loads are unconditional (clamped address + select), so the compiler batches them under one wait.
+// grid = (position blocks, channel groups, N); thread -> (channel-vec4 = tid % CG fastest, position = tid / CG).
+// POOL partial rows: pool[n][position block][C], each channel group fills its own channel slice.
+template <int K, int STR, int SW, int SH, bool POOL>
+__global__ __launch_bounds__(256) void dw_tile_kernel(const DwArgs p, int CG, int PB, int HS, int S) {
+  extern __shared__ float4 dw_smem[];          // weights [taps][CG], then (POOL) stage[256]
+  const int taps = p.kT * K * K;
+  float4* wl = dw_smem;
+  float4* stage = dw_smem + taps * CG;
+  const int tid = threadIdx.x;
+  const int n = blockIdx.z, g = blockIdx.y;
+  const int nblk = gridDim.x;
+  const int lb = xcd_remap(blockIdx.x, nblk);
+  for (int i = tid; i < taps * CG; i += 256) {
+    const int tap = i / CG, c = i - tap * CG;
+    wl[i] = *reinterpret_cast<const float4*>(p.w + (long)tap * p.C + (g * CG + c) * 4);
+  }
+  __syncthreads();
+  const int cvl = tid % CG, pl = tid / CG;
+  const long pos = (long)lb * PB + pl;
+  const long npos = (long)p.To * HS * S;
+  float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (pl < PB && pos < npos) {
+    const int ws = (int)(pos % S);
+    const int hs = (int)((pos / S) % HS);
+    const int to = (int)(pos / ((long)S * HS));
+    const int cv = g * CG + cvl;
+    const int wo0 = ws * SW, ho0 = hs * SH;
+    const int t0 = to * p.strT - p.padT, h0 = ho0 * STR - p.padH, w0 = wo0 * STR - p.padW;
+    const float* xb = p.x + ((long)n * p.T * p.H * p.W) * p.ldx + cv * 4;
+    const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + cv * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc[SH][SW];
+#pragma unroll
+    for (int sh = 0; sh < SH; ++sh)
+#pragma unroll
+      for (int o = 0; o < SW; ++o) acc[sh][o] = bv;
+    constexpr int NIN = (SW - 1) * STR + K, RIN = (SH - 1) * STR + K;
+    for (int dt = 0; dt < p.kT; ++dt) {
+      const int t = t0 + dt;
+      if ((unsigned)t >= (unsigned)p.T) continue;
+      const float4* wt = wl + (dt * K * K) * CG + cvl;
+#pragma unroll 1   // rolled: unrolled, the compiler hoists every row's loads and spills (1.6 KB scratch/lane, occupancy 1)
+      for (int r = 0; r < RIN; ++r) {
+        const int h = h0 + r;
+        const bool hv = (unsigned)h < (unsigned)p.H;
+        const float* xr = xb + ((long)(t * p.H + (hv ? h : 0)) * p.W) * p.ldx;
+        float4 xin[NIN];
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+          const int w = w0 + j;
+          const bool ok = hv && (unsigned)w < (unsigned)p.W;
+          const float4 v = *reinterpret_cast<const float4*>(xr + (long)(ok ? w : 0) * p.ldx);
+          xin[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int sh = 0; sh < SH; ++sh) {
+          const int dh = r - sh * STR;
+          if (dh < 0 || dh >= K) continue;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const float4 wv = wt[(dh * K + k) * CG];
+#pragma unroll
+            for (int o = 0; o < SW; ++o) {
+              const float4 xv = xin[o * STR + k];
+              acc[sh][o].x = fmaf(xv.x, wv.x, acc[sh][o].x);
+              acc[sh][o].y = fmaf(xv.y, wv.y, acc[sh][o].y);
+              acc[sh][o].z = fmaf(xv.z, wv.z, acc[sh][o].z);
+              acc[sh][o].w = fmaf(xv.w, wv.w, acc[sh][o].w);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int sh = 0; sh < SH; ++sh) {
+      if (ho0 + sh >= p.Ho) continue;
+      const long orow = (((long)n * p.To + to) * p.Ho + ho0 + sh) * p.Wo + wo0;
+#pragma unroll
+      for (int o = 0; o < SW; ++o) {
+        if (wo0 + o < p.Wo) {
+          float4 v = acc[sh][o];
+          if (POOL) { psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w; }
+          v.x = act_apply(v.x, p.act); v.y = act_apply(v.y, p.act); v.z = act_apply(v.z, p.act); v.w = act_apply(v.w, p.act);
+          *reinterpret_cast<float4*>(p.y + (orow + o) * p.ldy + cv * 4) = v;
+        }
+      }
+    }
+  }
+  if (POOL) {
+    stage[tid] = psum;
+    __syncthreads();
+    if (tid < CG) {   // fixed order over the block's positions: bitwise reproducible
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < PB; ++q) { const float4 v = stage[q * CG + tid]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+      *reinterpret_cast<float4*>(p.pool + ((long)n * nblk + lb) * p.C + (g * CG + tid) * 4) = s;
+    }
+  }
+}
+
+struct TileCfg { int K, STR, SW, SH, CG, G, PB, HS, S; long nblk; };
+
+// The tile kernel covers square (k, K, K) kernels, K in {3, 7}, equal H/W stride 1 (or 2 for K = 3).
+static bool tile_cfg(const MspiDwConvDesc* d, TileCfg& c) {
+  static const bool off = getenv("MSPI_DW_STRIP") != nullptr;   // A/B switch: the older strip kernel
+  if (off || d->kH != d->kW || d->strH != d->strW) return false;
+  if (!((d->kW == 3 && (d->strW == 1 || d->strW == 2)) || (d->kW == 7 && d->strW == 1))) return false;
+  static const bool all = getenv("MSPI_DW_TILE_ALL") != nullptr;
+  // measured (profiles/r01): the tile kernel wins on 7x7 with maps >= 28 wide (172 -> 134 us at 56^2 x 96), the strip
+  // kernel on 3x3x3 and on the small maps, where one round of blocks makes latency, not traffic, the cost
+  if (!all && !(d->kW == 7 && d->W >= 28)) return false;
+  const int Ho = (d->H + 2 * d->padH - d->kH) / d->strH + 1, Wo = (d->W + 2 * d->padW - d->kW) / d->strW + 1;
+  const int To = (d->T + 2 * d->padT - d->kT) / d->strT + 1;
+  c.K = d->kW; c.STR = d->strW;
+  c.SW = (Wo % 7 == 0) ? 7 : 4;
+  c.SH = 2;
+  const int CV = d->C / 4;
+  int g = 1;
+  while (CV % g != 0 || CV / g > 32) ++g;
+  c.G = g; c.CG = CV / g; c.PB = 256 / c.CG;
+  c.HS = (Ho + c.SH - 1) / c.SH; c.S = (Wo + c.SW - 1) / c.SW;
+  c.nblk = ((long)To * c.HS * c.S + c.PB - 1) / c.PB;
+  return c.nblk < (1L << 31) && c.G < 65536 && d->N < 65536;
 }
 
 constexpr int DW_SW = 4;  // strip length along W
@@ -202,6 +347,7 @@ using namespace mspi;
 
 // which strip instantiation serves this descriptor: 0 = (kW 3, stride 1), 1 = (3, 2), 2 = (7, 1), -1 = generic kernel
 static int strip_variant(const MspiDwConvDesc* d) {
+  if (d->kH != d->kW) return -1;
   if (d->kW == 3 && d->strW == 1) return 0;
   if (d->kW == 3 && d->strW == 2) return 1;
   if (d->kW == 7 && d->strW == 1) return 2;
@@ -220,7 +366,20 @@ extern "C" int mspi_dwconv_fwd(const MspiDwConvDesc* d, const float* x, const fl
   hipStream_t s = (hipStream_t)stream;
   const int strip = strip_variant(d);
   MSPI_REQUIRE(!pool || strip >= 0, "mspi_dwconv_fwd: SE pooling needs a (k,3,3)/(k,7,7) kernel with W-stride 1 or 2");
-  if (strip >= 0) {
+  TileCfg tc;
+  if (tile_cfg(d, tc)) {
+    const dim3 grid((unsigned)tc.nblk, (unsigned)tc.G, (unsigned)a.N);
+    const size_t lds = ((size_t)a.kT * tc.K * tc.K * tc.CG + (pool ? 256 : 0)) * sizeof(float4);
+#define MSPI_DWT(KK, ST, SWW)                                                                                            \
+    do {                                                                                                                 \
+      if (pool) hipLaunchKernelGGL((dw_tile_kernel<KK, ST, SWW, 2, true>), grid, dim3(256), lds, s, a, tc.CG, tc.PB, tc.HS, tc.S);  \
+      else hipLaunchKernelGGL((dw_tile_kernel<KK, ST, SWW, 2, false>), grid, dim3(256), lds, s, a, tc.CG, tc.PB, tc.HS, tc.S);      \
+    } while (0)
+    if (tc.K == 7) { if (tc.SW == 7) MSPI_DWT(7, 1, 7); else MSPI_DWT(7, 1, 4); }
+    else if (tc.STR == 1) { if (tc.SW == 7) MSPI_DWT(3, 1, 7); else MSPI_DWT(3, 1, 4); }
+    else { if (tc.SW == 7) MSPI_DWT(3, 2, 7); else MSPI_DWT(3, 2, 4); }
+#undef MSPI_DWT
+  } else if (strip >= 0) {
     const long S = (a.Wo + DW_SW - 1) / DW_SW;
     const long per = (long)a.To * a.Ho * S * a.CV;
     dim3 grid((unsigned)((per + 255) / 256), (unsigned)a.N);
@@ -244,6 +403,8 @@ extern "C" int mspi_dwconv_fwd(const MspiDwConvDesc* d, const float* x, const fl
 
 extern "C" int mspi_dwconv_pool_rows(const MspiDwConvDesc* d) {
   if (!d || strip_variant(d) < 0) return -1;
+  TileCfg tc;
+  if (tile_cfg(d, tc)) return (int)tc.nblk;
   const long Wo = (d->W + 2 * d->padW - d->kW) / d->strW + 1;
   const long S = (Wo + DW_SW - 1) / DW_SW;
   const long per = (long)d->To * d->Ho * S * (d->C / 4);
