@@ -255,6 +255,30 @@ size_t mspi_mlp_packed_bytes(int32_t C, int32_t hidden);
 int mspi_mlp_fwd(const MspiMlpDesc* d, const void* x, const void* gamma, const void* beta, const void* w_packed,
                  const void* b1, const void* b2, const void* res, void* y, mspi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Row-stationary thin GEMM (1x1x1 conv / Linear with K <= 224 and few output columns):
+ *   y[M, N] = act( x'[M, K] . W^T + bias (+ res) ),   x' = x, or swish(x * gate[row / rows_per_sample]) when gate != NULL.
+ * Same contract as mspi_conv_fwd on a dense 1x1x1 stride-1 problem; a different kernel (csrc/mlp_fused.hip) and a
+ * different weight packing.  Replaces: X3DTransform.a / .c (SlowFast/resnet_helper.py:296-351, with the SE scale :333
+ * and Swish :339 as the gate prologue), ResBlock.branch1 (:540-556), X3D conv5 pieces (backbones/X3D.py).
+ * K, N: storage columns of x / y (multiples of 4, pad columns zero).  mspi_rowgemm_supported(K, N) says whether the
+ * shape is covered (K <= 224, N <= 1024).
+ * w_packed: mspi_rowgemm_packed_bytes(K, N) bytes of f16; with KSB = 2, 4, 8 or 14 k-steps of 16 (the smallest
+ * covering K) and Ws = w_scale * W [N, K] zero-padded:  [chunk j < ceil(N/32)][ks < KSB][hi,lo][lane < 64][e < 8]
+ *   = Ws[j*32 + lane%32][16 ks + 8 (lane/32) + e]   (engine.pack_rowgemm builds it). */
+typedef struct {
+  int64_t M;
+  int32_t K, N;
+  int64_t ldx, ldr, ldy, ldg;   /* row strides in floats (ldg: gate rows) */
+  int32_t act;
+  int32_t rows_per_sample;      /* gate row index = row / rows_per_sample */
+  float w_scale;
+} MspiRowGemmDesc;
+size_t mspi_rowgemm_packed_bytes(int32_t K, int32_t N);
+int mspi_rowgemm_supported(int32_t K, int32_t N);
+int mspi_rowgemm_fwd(const MspiRowGemmDesc* d, const void* x, const void* w_packed, const void* bias, const void* res,
+                     const void* gate, void* y, mspi_stream_t stream);
+
 /* y = a + b over n floats (plain residual add where no producer can fuse it). */
 int mspi_add(const float* a, const float* b, float* y, int64_t n, mspi_stream_t stream);
 

@@ -76,6 +76,14 @@ class MlpDesc(C.Structure):
     ]
 
 
+class RowGemmDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int64), ("K", C.c_int32), ("N", C.c_int32),
+        ("ldx", C.c_int64), ("ldr", C.c_int64), ("ldy", C.c_int64), ("ldg", C.c_int64),
+        ("act", C.c_int32), ("rows_per_sample", C.c_int32), ("w_scale", C.c_float),
+    ]
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -100,6 +108,9 @@ _SIGNATURES = {
     "mspi_mean_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mspi_neg_cosine": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P]),
     "mspi_add": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "mspi_rowgemm_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "mspi_rowgemm_supported": (C.c_int, [C.c_int32, C.c_int32]),
+    "mspi_rowgemm_fwd": (C.c_int, [C.POINTER(RowGemmDesc), _P, _P, _P, _P, _P, _P, _P]),
     "mspi_mlp_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "mspi_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mspi_postprocess_workspace": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -275,3 +275,200 @@ extern "C" int mspi_mlp_fwd(const MspiMlpDesc* d, const void* x, const void* gam
   (void)rc;
   return check_launch("mspi_mlp_fwd");
 }
+
+// =====================================================================================================
+// Row-stationary thin GEMM:  y[M, N] = act( x[M, K] . W^T + bias (+ res) )  for K <= 224, N small (X3D's 1x1x1 layers).
+//
+// The tiled implicit GEMM is the wrong tool for these layers: K = 24..216 is 1-7 pipeline steps, so a workgroup is
+// prologue + epilogue and the kernel is one exposed memory latency after another (17-25 us for 30 MB of traffic,
+// profiles/r01).  Here -- phase 1 of the fused MLP above, with a store epilogue -- a wave loads its 32 rows ONCE
+// (optionally x <- swish(x * gate[sample]): the squeeze-excite prologue of X3D's `c` conv), keeps them as f16 hi/lo MFMA
+// B-operand fragments, and walks the output columns in chunks of 32:  Y^T chunk = W[chunk rows][:] . X^T.  All weights
+// (fragment order, engine.pack_rowgemm) are brought into LDS by one burst of LDS-DMA at kernel start, so after the
+// single load phase the kernel only computes and stores.
+namespace mspi {
+
+struct RowGemmArgs {
+  const float* x; const unsigned char* wp; const float* bias; const float* res; const float* gate; float* y;
+  long M, ldx, ldr, ldy, ldg;
+  int K, N;           // storage columns of x / y (multiples of 4)
+  int nch;            // ceil(N / 32)
+  int cps;            // chunks per workgroup: grid.y workgroups share a row tile and split the output columns
+  int act;
+  float inv_s;
+  int rows_per_sample;
+};
+
+template <int KSB, bool GATE>
+__global__ __launch_bounds__(256, 2) void rowgemm_kernel(const RowGemmArgs p) {
+  constexpr int SB = KSB * 2048;                 // bytes of one 32-column chunk: [ks][hi,lo][lane][8 halves]
+  extern __shared__ __attribute__((aligned(16))) unsigned char rg_smem[];   // cps * SB weights, then cps*32 bias floats
+  const int j0 = blockIdx.y * p.cps;
+  const int nj = min(p.cps, p.nch - j0);
+  float* bs = reinterpret_cast<float*>(rg_smem + (size_t)p.cps * SB);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const long row = (long)blockIdx.x * 128 + wave * 32 + li;
+  const bool rok = row < p.M;
+  const long rr = rok ? row : p.M - 1;
+
+  // weights of this workgroup's chunks: nj*SB/1024 pieces of 1 KB, dealt round-robin to the 4 waves
+  const int pieces = nj * (SB / 1024);
+  for (int i = wave; i < pieces; i += 4)
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(p.wp + (long)j0 * SB + (long)i * 1024 + lane * 16),
+                                     (lds_void*)(rg_smem + (long)i * 1024), 16, 0, 0);
+  // rows
+  float xr[KSB][8];
+  const float* xp = p.x + rr * p.ldx + 8 * lh;
+#pragma unroll
+  for (int ks = 0; ks < KSB; ++ks) {
+    const int k = 16 * ks + 8 * lh;
+    const bool k0 = k < p.K, k1 = k + 4 < p.K;
+    const float4 a = *reinterpret_cast<const float4*>(xp + (k0 ? 16 * ks : -8 * lh));
+    const float4 b = *reinterpret_cast<const float4*>(xp + (k1 ? 16 * ks + 4 : -8 * lh));
+    xr[ks][0] = k0 ? a.x : 0.f; xr[ks][1] = k0 ? a.y : 0.f; xr[ks][2] = k0 ? a.z : 0.f; xr[ks][3] = k0 ? a.w : 0.f;
+    xr[ks][4] = k1 ? b.x : 0.f; xr[ks][5] = k1 ? b.y : 0.f; xr[ks][6] = k1 ? b.z : 0.f; xr[ks][7] = k1 ? b.w : 0.f;
+  }
+  if (GATE) {
+    const float* gp = p.gate + (rr / p.rows_per_sample) * p.ldg + 8 * lh;
+#pragma unroll
+    for (int ks = 0; ks < KSB; ++ks) {
+      const int k = 16 * ks + 8 * lh;
+      const bool k0 = k < p.K, k1 = k + 4 < p.K;
+      const float4 a = *reinterpret_cast<const float4*>(gp + (k0 ? 16 * ks : -8 * lh));
+      const float4 b = *reinterpret_cast<const float4*>(gp + (k1 ? 16 * ks + 4 : -8 * lh));
+      const float g8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = xr[ks][e] * g8[e];
+        xr[ks][e] = v / (1.f + __expf(-v));     // Swish (zero stays zero: masked k contribute nothing)
+      }
+    }
+  }
+  for (int i = tid; i < nj * 32; i += 256) bs[i] = (p.bias && j0 * 32 + i < p.N) ? p.bias[j0 * 32 + i] : 0.f;
+  v8h xh[KSB], xl[KSB];
+#pragma unroll
+  for (int ks = 0; ks < KSB; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const _Float16 h = (_Float16)xr[ks][e];
+      xh[ks][e] = h;
+      xl[ks][e] = (_Float16)(xr[ks][e] - (float)h);
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int jl = 0; jl < nj; ++jl) {
+    const int j = j0 + jl;
+    const unsigned char* st = rg_smem + (long)jl * SB + lane * 16;
+    v16f h;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) h[i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSB; ++ks) {
+      const v8h wh = *reinterpret_cast<const v8h*>(st + (ks * 2 + 0) * 1024);
+      const v8h wl = *reinterpret_cast<const v8h*>(st + (ks * 2 + 1) * 1024);
+      h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[ks], h, 0, 0, 0);
+      h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[ks], h, 0, 0, 0);
+      h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[ks], h, 0, 0, 0);
+    }
+    // lane (li, lh) holds, for row li, columns j*32 + q*8 + 4*lh + 0..3
+    float4 rv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = j * 32 + q * 8 + 4 * lh;
+      rv[q] = (p.res && c < p.N) ? *reinterpret_cast<const float4*>(p.res + rr * p.ldr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = j * 32 + q * 8 + 4 * lh;
+      const float4 b = *reinterpret_cast<const float4*>(bs + c - j0 * 32);
+      float4 v;
+      v.x = fmaf(h[q * 4 + 0], p.inv_s, b.x) + rv[q].x;
+      v.y = fmaf(h[q * 4 + 1], p.inv_s, b.y) + rv[q].y;
+      v.z = fmaf(h[q * 4 + 2], p.inv_s, b.z) + rv[q].z;
+      v.w = fmaf(h[q * 4 + 3], p.inv_s, b.w) + rv[q].w;
+      if (p.act == MSPI_ACT_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      } else if (p.act != MSPI_ACT_NONE) {
+        v.x = act_apply(v.x, p.act); v.y = act_apply(v.y, p.act); v.z = act_apply(v.z, p.act); v.w = act_apply(v.w, p.act);
+      }
+      if (rok && c < p.N) *reinterpret_cast<float4*>(p.y + row * p.ldy + c) = v;
+    }
+  }
+}
+
+template <int KSB>
+static int launch_rowgemm(const RowGemmArgs& a, size_t lds, hipStream_t s) {
+  static bool attr_done = false;   // > 64 KB of dynamic LDS is an opt-in, once per instantiation
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<KSB, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<KSB, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) {
+      (void)hipGetLastError();
+      return -1;
+    }
+    attr_done = true;
+  }
+  const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.nch + a.cps - 1) / a.cps));
+  if (a.gate) hipLaunchKernelGGL((rowgemm_kernel<KSB, true>), grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((rowgemm_kernel<KSB, false>), grid, dim3(256), lds, s, a);
+  return 0;
+}
+
+}  // namespace mspi
+
+static int rowgemm_ksb(int K) { return K <= 32 ? 2 : K <= 64 ? 4 : K <= 128 ? 8 : K <= 224 ? 14 : 0; }
+
+extern "C" size_t mspi_rowgemm_packed_bytes(int32_t K, int32_t N) {
+  const int ksb = rowgemm_ksb(K);
+  return ksb ? (size_t)((N + 31) / 32) * ksb * 2048 : 0;
+}
+
+// chunks per workgroup: all of them when the row tiles alone fill the chip; otherwise the output columns are split over
+// grid.y so that (a) the grid reaches ~2 workgroups per CU and (b) a workgroup's weights fit in LDS with room for a neighbour
+static int rowgemm_cps(long M, int nch, int ksb) {
+  const long row_tiles = (M + 127) / 128;
+  int split = 1;
+  if (row_tiles < 512) split = (int)((512 + row_tiles - 1) / row_tiles);
+  if (split > nch) split = nch;
+  int cps = (nch + split - 1) / split;
+  const int cap = (72 * 1024) / (ksb * 2048 + 128);   // <= 72 KB of LDS per workgroup
+  if (cps > cap) cps = cap;
+  return cps < 1 ? 1 : cps;
+}
+
+extern "C" int mspi_rowgemm_supported(int32_t K, int32_t N) {
+  return rowgemm_ksb(K) != 0 && N >= 4 && N <= 1024;
+}
+
+extern "C" int mspi_rowgemm_fwd(const MspiRowGemmDesc* d, const void* x, const void* w_packed, const void* bias, const void* res,
+                                const void* gate, void* y, void* stream) {
+  MSPI_REQUIRE(d && x && w_packed && y, "mspi_rowgemm_fwd: null argument");
+  MSPI_REQUIRE(d->M >= 1 && d->M < (1L << 31) && d->K >= 4 && d->N >= 4 && d->K % 4 == 0 && d->N % 4 == 0,
+               "mspi_rowgemm_fwd: M = %ld, K = %d, N = %d (K, N: storage columns, multiples of 4)", (long)d->M, d->K, d->N);
+  MSPI_REQUIRE(mspi_rowgemm_supported(d->K, d->N), "mspi_rowgemm_fwd: K = %d / N = %d outside the thin-GEMM range", d->K, d->N);
+  MSPI_REQUIRE(d->ldx >= d->K && d->ldy >= d->N && d->ldx % 4 == 0 && d->ldy % 4 == 0 && (!res || (d->ldr >= d->N && d->ldr % 4 == 0)),
+               "mspi_rowgemm_fwd: row strides must cover the row and be multiples of 4 floats");
+  MSPI_REQUIRE(!gate || (d->rows_per_sample > 0 && d->ldg >= d->K && d->ldg % 4 == 0), "mspi_rowgemm_fwd: gate needs rows_per_sample and ldg");
+  MSPI_REQUIRE(d->w_scale > 0.f, "mspi_rowgemm_fwd: w_scale must be positive");
+  RowGemmArgs a;
+  a.x = (const float*)x; a.wp = (const unsigned char*)w_packed; a.bias = (const float*)bias; a.res = (const float*)res;
+  a.gate = (const float*)gate; a.y = (float*)y;
+  a.M = d->M; a.ldx = d->ldx; a.ldr = d->ldr; a.ldy = d->ldy; a.ldg = d->ldg;
+  a.K = d->K; a.N = d->N; a.nch = (d->N + 31) / 32; a.act = d->act; a.inv_s = 1.0f / d->w_scale;
+  a.rows_per_sample = d->rows_per_sample;
+  const int ksb = rowgemm_ksb(d->K);
+  a.cps = rowgemm_cps(d->M, a.nch, ksb);
+  const size_t lds = (size_t)a.cps * (ksb * 2048 + 128);
+  int rc;
+  switch (ksb) {
+    case 2: rc = launch_rowgemm<2>(a, lds, (hipStream_t)stream); break;
+    case 4: rc = launch_rowgemm<4>(a, lds, (hipStream_t)stream); break;
+    case 8: rc = launch_rowgemm<8>(a, lds, (hipStream_t)stream); break;
+    default: rc = launch_rowgemm<14>(a, lds, (hipStream_t)stream); break;
+  }
+  MSPI_REQUIRE(rc == 0, "mspi_rowgemm_fwd: could not reserve %zu bytes of LDS", lds);
+  return check_launch("mspi_rowgemm_fwd");
+}

@@ -77,13 +77,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // One workgroup per sample.  pool holds `rows` partial sums per channel (one per dwconv block, fixed order):
 // they are summed here in a fixed order too (thread groups over row ranges, then a serial combine), so the
 // squeeze-excite path is bitwise reproducible.  Then fc1 (C->F) by wavefront-reduced dots, ReLU, fc2, sigmoid.
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ pool, int rows, float inv_count,
+__global__ __launch_bounds__(1024) void se_gate_kernel(const float* __restrict__ pool, int rows, float inv_count,
                                                       const float* __restrict__ w1, const float* __restrict__ b1,
                                                       const float* __restrict__ w2, const float* __restrict__ b2,
                                                       float* __restrict__ gate, int C, int F) {
   extern __shared__ float sm[];  // [G*C] partial sums, then [C] means, [F] hidden
   const int n = blockIdx.x;
-  const int G = C <= 256 ? 256 / C : 1;   // row groups
+  const int G = C <= 1024 ? 1024 / C : 1;   // row groups: 1024 threads, because the kernel is one latency chain per
+                                            // thread (189 partial rows at C = 216: 24 dependent load batches with 256 threads)
   float* part = sm;
   float* mean = sm + G * C;
   float* hid = mean + C;
@@ -104,24 +105,24 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
     const int c = threadIdx.x % C, g = threadIdx.x / C;
     if (g < G) part[g * C + c] = col_sum(c, g, G);
   } else {
-    for (int c = threadIdx.x; c < C; c += 256) part[c] = col_sum(c, 0, 1);
+    for (int c = threadIdx.x; c < C; c += 1024) part[c] = col_sum(c, 0, 1);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += 1024) {
     float s = 0.f;
     for (int g = 0; g < G; ++g) s += part[g * C + c];
     mean[c] = s * inv_count;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int f = wave; f < F; f += 4) {
+  for (int f = wave; f < F; f += 16) {
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s = fmaf(w1[(long)f * C + c], mean[c], s);
     s = wave_sum(s);
     if (lane == 0) hid[f] = fmaxf(s + b1[f], 0.f);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += 1024) {
     float s = b2[c];
     for (int f = 0; f < F; ++f) s = fmaf(w2[(long)c * F + f], hid[f], s);
     gate[(long)n * C + c] = 1.f / (1.f + __expf(-s));
@@ -330,10 +331,10 @@ extern "C" int mspi_se_gate(const float* pool, int32_t rows, float inv_count, co
                             const float* w2, const float* b2, float* gate, int32_t N, int32_t C, int32_t F,
                             mspi_stream_t stream) {
   MSPI_REQUIRE(pool && w1 && b1 && w2 && b2 && gate, "mspi_se_gate: null argument");
-  const int G = C <= 256 ? 256 / C : 1;
+  const int G = C <= 1024 ? 1024 / C : 1;
   const size_t lds = (size_t)(G * C + C + F) * sizeof(float);
   MSPI_REQUIRE(N > 0 && rows > 0 && C > 0 && F > 0 && lds <= 64 * 1024, "mspi_se_gate: bad extent");
-  hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), lds, (hipStream_t)stream, pool, rows, inv_count, w1, b1, w2,
+  hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(1024), lds, (hipStream_t)stream, pool, rows, inv_count, w1, b1, w2,
                      b2, gate, C, F);
   return check_launch("mspi_se_gate");
 }

@@ -60,16 +60,20 @@ def load_autotune(path):
     return len(AUTOTUNE["cache"])
 
 
-def _tune_conv(lib, d, args, key, candidates):
+THIN = 100            # kernel choice "row-stationary thin GEMM" next to MspiConvDesc.tile codes 0..11
+THIN_DEFAULT = True   # without autotuning: take the thin kernel wherever it applies
+THIN_ENABLED = _os.environ.get("MSPI_THIN", "1") != "0"   # A/B switch
+
+
+def _tune_conv(launch, key, candidates):
     best, best_t = -1, float("inf")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for tile in candidates:
-        d.tile = tile
-        if lib.mspi_conv_fwd(C.byref(d), *args) != 0:
+        if launch(tile) != 0:
             continue
         e0.record()
         for _ in range(AUTOTUNE["reps"]):
-            lib.mspi_conv_fwd(C.byref(d), *args)
+            launch(tile)
         e1.record()
         e1.synchronize()
         t = e0.elapsed_time(e1)
@@ -214,7 +218,7 @@ def fold_bn(weight, bias, bn):
 
 
 class PackedConv:
-    __slots__ = ("w", "bias", "k", "stride", "pad", "cin", "cin_s", "cout", "cout_s", "ldw", "act", "prec", "w_scale")
+    __slots__ = ("w", "bias", "k", "stride", "pad", "cin", "cin_s", "cout", "cout_s", "ldw", "act", "prec", "w_scale", "thin")
 
 
 def pack_conv(weight, bias=None, bn=None, stride=(1, 1, 1), pad=(0, 0, 0), act=ACT_NONE, cin_stored=None,
@@ -242,6 +246,7 @@ def pack_conv(weight, bias=None, bn=None, stride=(1, 1, 1), pad=(0, 0, 0), act=A
     wf = torch.zeros(cout_s, ldw, dtype=torch.float32, device=w.device)
     wf[:, :K] = wp.reshape(cout_s, K)
     p = PackedConv()
+    p.thin = None
     dev = w.device if device is None else device
     p.prec, p.w_scale = prec, 1.0
     if prec == PREC_F16X3:
@@ -255,6 +260,8 @@ def pack_conv(weight, bias=None, bn=None, stride=(1, 1, 1), pad=(0, 0, 0), act=A
         hi = ws.to(torch.float16)
         lo = (ws - hi.float()).to(torch.float16)
         p.w = torch.stack([hi, lo]).to(dev).contiguous()
+        if (kt, kh, kw) == (1, 1, 1) and tuple(stride) == (1, 1, 1) and tuple(pad) == (0, 0, 0):
+            p.thin = _pack_rowgemm(ws[:, :K], cin_s, cout_s, dev)
     else:
         p.w = wf.to(dev).contiguous()
     if b is None:
@@ -266,6 +273,30 @@ def pack_conv(weight, bias=None, bn=None, stride=(1, 1, 1), pad=(0, 0, 0), act=A
     p.k, p.stride, p.pad = (kt, kh, kw), tuple(stride), tuple(pad)
     p.cin, p.cin_s, p.cout, p.cout_s, p.ldw, p.act = ci, cin_s, co, cout_s, ldw, act
     return p
+
+
+def rowgemm_ksb(k):
+    """k-steps of 16 the row-stationary thin GEMM keeps in registers for K stored input columns (0: not covered)."""
+    return 2 if k <= 32 else 4 if k <= 64 else 8 if k <= 128 else 14 if k <= 224 else 0
+
+
+def rowgemm_supported(k, n):
+    """Mirror of mspi_rowgemm_supported."""
+    return bool(rowgemm_ksb(k)) and 4 <= n <= 1024
+
+
+def _pack_rowgemm(ws, k_s, n_s, dev):
+    """Scaled weights ws [n_s, k_s] -> fragment-order f16 hi/lo planes for mspi_rowgemm_fwd (layout: include/mspi_hip.h);
+    None when the shape is outside the kernel's range."""
+    if not rowgemm_supported(k_s, n_s):
+        return None
+    ksb, nch = rowgemm_ksb(k_s), (n_s + 31) // 32
+    wp = torch.zeros(nch * 32, ksb * 16, dtype=torch.float32)
+    wp[:n_s, :k_s] = ws.cpu()
+    hi = wp.to(torch.float16)
+    lo = (wp - hi.float()).to(torch.float16)
+    planes = [pl.view(nch, 32, ksb, 2, 8).permute(0, 2, 3, 1, 4).reshape(nch, ksb, 64, 8) for pl in (hi, lo)]
+    return torch.stack(planes, 2).contiguous().to(dev)      # [nch, ksb, plane, lane, 8]
 
 
 class PackedMlp:
@@ -403,28 +434,51 @@ def conv(x, pk, out=None, res=None, gate=None, act=None, tile=None):
                                                   " +res" if res is not None else "", " +gate" if gate is not None else ""))
     args = (xptr, pk.w.data_ptr(), pk.bias.data_ptr() if pk.bias is not None else None,
             res.ptr if res is not None else None, gate.data_ptr() if gate is not None else None, out.ptr, _stream())
-    d.tile = -1
+    # the row-stationary thin GEMM (mspi_rowgemm_fwd) is a second implementation of dense 1x1x1 layers with K <= 224:
+    # kernel choice THIN competes with the tile codes of mspi_conv_fwd in the autotuner
+    rg = None
+    if THIN_ENABLED and pk.thin is not None and isinstance(x, CL) and x.dense:
+        rg = _lib.RowGemmDesc()
+        rg.M, rg.K, rg.N = M, pk.cin_s, pk.cout_s
+        rg.ldx, rg.ldy, rg.ldr, rg.ldg = x.ld, out.ld, d.ldr, pk.cin_s
+        rg.act, rg.rows_per_sample, rg.w_scale = d.act, To * Ho * Wo, pk.w_scale
+        rg_args = (xptr, pk.thin.data_ptr(), args[2], args[3], args[4], out.ptr, args[6])
+
+    def launch(t):
+        if t == THIN:
+            return lib.mspi_rowgemm_fwd(C.byref(rg), *rg_args)
+        d.tile = t
+        return lib.mspi_conv_fwd(C.byref(d), *args)
+
+    choice = -1
+    key = (M, taps * pk.cin_s, pk.cout_s, pk.k, pk.stride, pk.prec, d.sC == 1, res is not None, gate is not None, rg is not None)
     if tile is not None:
-        d.tile = tile
+        choice = tile
     elif AUTOTUNE["on"] and not torch.cuda.is_current_stream_capturing():
-        key = (M, taps * pk.cin_s, pk.cout_s, pk.k, pk.stride, pk.prec, d.sC == 1, res is not None, gate is not None)
-        tile = AUTOTUNE["cache"].get(key)
-        if tile is None:
+        choice = AUTOTUNE["cache"].get(key)
+        if choice is None:
             cands = [1, 2, 3, 4]
             if pk.prec == PREC_F16X3 and d.sC == 1 and Cin % 4 == 0:
                 cands += [6, 7, 9, 10] + ([8] if pk.cout_s <= 256 else [])
-            tile = _tune_conv(lib, d, args, key, cands)
-        d.tile = tile
-    elif AUTOTUNE["cache"]:
-        key = (M, taps * pk.cin_s, pk.cout_s, pk.k, pk.stride, pk.prec, d.sC == 1, res is not None, gate is not None)
-        d.tile = AUTOTUNE["cache"].get(key, -1)
+            if rg is not None:
+                cands.append(THIN)
+            choice = _tune_conv(launch, key, cands)
+    elif key in AUTOTUNE["cache"]:
+        choice = AUTOTUNE["cache"][key]
+    elif rg is not None and THIN_DEFAULT:
+        choice = THIN
+    if choice == THIN and rg is None:
+        raise MspiError("conv: the thin-GEMM kernel does not cover this call")
     with tm:
-        check(lib.mspi_conv_fwd(C.byref(d), *args), "mspi_conv_fwd")
+        check(launch(choice), "mspi_rowgemm_fwd" if choice == THIN else "mspi_conv_fwd")
         if Profiler.active is not None:
-            c = lib.mspi_conv_last_config()
-            tm.name = "conv_gemm<%d,%d,%s,%s>" % (c >> 16, (c >> 4) & 0xFFF,
-                                                  "dma" if c & 4 else ("s" if c & 1 else "v4") + ("w8" if c & 8 else ""),
-                                                  "f16x3" if (c >> 1) & 1 else "f32")
+            if choice == THIN:
+                tm.name = "rowgemm<%d,f16x3>" % rowgemm_ksb(pk.cin_s)
+            else:
+                c = lib.mspi_conv_last_config()
+                tm.name = "conv_gemm<%d,%d,%s,%s>" % (c >> 16, (c >> 4) & 0xFFF,
+                                                      "dma" if c & 4 else ("s" if c & 1 else "v4") + ("w8" if c & 8 else ""),
+                                                      "f16x3" if (c >> 1) & 1 else "f32")
     return out
 
 

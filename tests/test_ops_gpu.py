@@ -395,3 +395,45 @@ def test_mlp_fused(dev, C, M, ln, res):
     fc2 = E.pack_conv(w2, b2, out_scale=ls, device=dev)
     out2 = E.conv(E.conv(y, fc1), fc2, res=rc)
     _close(out.as_rows(), out2.as_rows().cpu(), 2e-5, "fused vs unfused")
+
+
+@pytest.mark.parametrize("cin,cout,M,res,gate,act", [
+    (24, 54, 1000, False, False, 1), (54, 24, 333, True, True, 1), (96, 216, 777, False, False, 1),
+    (216, 96, 515, True, True, 0), (108, 48, 128, True, False, 1), (192, 432, 260, False, False, 0),
+    (96, 216, 70000, False, False, 1),
+    (48, 108, 31, False, False, 4)])
+def test_rowgemm_thin(dev, cin, cout, M, res, gate, act):
+    """mspi_rowgemm_fwd (kernel choice THIN of engine.conv): X3D's 1x1x1 layers incl. the SE-gate + Swish prologue,
+    the residual epilogue, channel counts that are not multiples of 4 (54 -> 56 stored) and ragged M."""
+    from mspi_amd import engine as E
+    if E.DEFAULT_PREC != E.PREC_F16X3:
+        pytest.skip("the thin GEMM is an f16x3 kernel")
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    N, rows = 3, (M + 2) // 3
+    x = torch.randn(N, cin, 1, rows, 1, generator=g)
+    w = torch.randn(cout, cin, 1, 1, 1, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(N, cout, 1, rows, 1, generator=g) if res else None
+    gt = torch.rand(N, cin, generator=g) * 2 if gate else None
+    xin = x.double()
+    if gate:
+        xin = F.silu(xin * gt.double()[:, :, None, None, None])
+    ref = F.conv3d(xin, w.double(), b.double())
+    if res:
+        ref = ref + r.double()
+    ref = {0: ref, 1: F.relu(ref), 4: F.silu(ref)}[act]
+    from mspi_amd.module import to_cl
+    xc = to_cl(x.to(dev))
+    pk = E.pack_conv(w, b, act=act, cin_stored=xc.Cs, device=dev)
+    assert pk.thin is not None
+    rc = to_cl(r.to(dev)) if res else None
+    gd = None
+    if gate:
+        gd = torch.zeros(N, xc.Cs, device=dev)
+        gd[:, :cin] = gt.to(dev)
+    out = E.conv(xc, pk, res=rc, gate=gd, tile=E.THIN)
+    _close(out.as_ncdhw(), ref.float(), 2e-5, "thin gemm")
+    out2 = E.conv(xc, pk, res=rc, gate=gd, tile=3)
+    _close(out.as_ncdhw(), out2.as_ncdhw().cpu(), 2e-5, "thin vs tiled")
+    if out.Cs > cout:   # pad channels stay exact zeros
+        assert (out.as_rows()[:, cout:] == 0).all()
