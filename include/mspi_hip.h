@@ -146,7 +146,7 @@ int mspi_layernorm_fwd(const float* x, int64_t ldx, int64_t sNx, float* y, int64
                        int32_t act, const float* table /*NULL or [R][C]*/, mspi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
- * Fused multi-head attention (flash style, MFMA, online softmax, fp32):
+ * Fused multi-head attention (flash style, MFMA, online softmax, fp32 in / fp32 accumulate):
  *   o[b,h,i,:] = softmax_j( scale * q[b,h,i,:] . k[b,h,j,:] + biasT[h,j,i] + maskT[b % nmask,j,i] ) v[b,h,j,:] (+ res)
  * q/k/v/o (and res, with o's strides) are addressed as base + b*sB + h*sH + token*sT + d (d contiguous).
  * D = head dim of q/k, Dv = head dim of v/o; (D,Dv) in {(32,32),(64,64),(96,96),(128,128),(128,96),(160,96)}.
@@ -165,6 +165,7 @@ typedef struct MspiAttnDesc {
   int64_t v_sB, v_sH, v_sT;
   int64_t o_sB, o_sH, o_sT;
   float scale;
+  int32_t prec;   /* MSPI_PREC_F32: fp32 MFMA; MSPI_PREC_F16X3: split products on the f16 pipe (fp32-accurate) */
 } MspiAttnDesc;
 
 int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float* k, const float* v, const float* res,

@@ -54,7 +54,7 @@ class AttnDesc(C.Structure):
         ("k_sB", C.c_int64), ("k_sH", C.c_int64), ("k_sT", C.c_int64),
         ("v_sB", C.c_int64), ("v_sH", C.c_int64), ("v_sT", C.c_int64),
         ("o_sB", C.c_int64), ("o_sH", C.c_int64), ("o_sT", C.c_int64),
-        ("scale", C.c_float),
+        ("scale", C.c_float), ("prec", C.c_int32),
     ]
 
 

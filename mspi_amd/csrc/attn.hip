@@ -178,6 +178,220 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   }
 }
 
+// ------------------------------------------------------------------ the same attention on the f16 matrix pipe
+// f16x3 split products (see conv_common.h): every operand x = hi + lo in f16, x.y = hi.hi + hi.lo + lo.hi accumulated
+// in fp32 by v_mfma_f32_32x32x16_f16 -- fp32-accurate, 48 MFMA x 32 cycles per (32 queries x 32 keys x 128 d) tile instead
+// of 128 x 64 cycles on the fp32 pipe.  Differences to attn_kernel above:
+//   * K is staged as two f16 planes [key][D] (rows padded by 8 halves: conflict-free ds_read_b128), Q is split once into
+//     registers as the B operand of S^T = K . Q^T;
+//   * V is staged TRANSPOSED as two f16 planes Vt[d][key] (36-half rows): the A operand of O^T += V^T . P^T needs, per
+//     lane (d, half), 8 keys of one column d.  The key <-> k-slot order is free as long as both operands agree, so it is
+//     chosen to be the order in which the S^T accumulator already holds the probabilities:
+//         k-slot (step s, half h, e)  <->  key 16 s + 8 (e >> 2) + 4 h + (e & 3)
+//     i.e. P needs no movement at all (registers 8s .. 8s+7 of the accumulator, split hi/lo in place), and the V^T
+//     fragment is two 8-byte reads of row d (keys 16s+4h .. +3 and 16s+8+4h .. +3).
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split4(const float4 v, v4h& hi, v4h& lo) {
+  const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    _Float16 h, l;
+    split_f16(a[e], h, l);
+    hi[e] = h; lo[e] = l;
+  }
+}
+
+template <int D, int DV>
+__global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
+  constexpr int KP = D + 8;     // K plane row pitch (halves)
+  constexpr int VP = 36;        // Vt plane row pitch (halves): 32 keys + 4
+  constexpr int NS = D / 16;    // k16 steps of S
+  constexpr int NT = DV / 32;   // 32-wide output tiles along d
+  // Power-of-two operand scales (exact; undone on the fp32 side).  The lo half of a split value is ~2^-12 of it, and
+  // f16 loses precision below 2^-14 (subnormals; the matrix pipe may flush them): q*scale ~ 0.1 and p <= 1 would keep
+  // only their hi halves.  Scaled, every operand of ordinary magnitude has a NORMAL lo half.
+  constexpr float QSC = 64.f, KSC = 16.f, PSC = 1024.f, VSC = 16.f;
+  __shared__ __attribute__((aligned(16))) _Float16 smem[2 * 32 * KP + 2 * DV * VP];
+  _Float16* Kh = smem;
+  _Float16* Kl = smem + 32 * KP;
+  _Float16* Vh = smem + 2 * 32 * KP;
+  _Float16* Vl = Vh + DV * VP;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y / p.Hh, h = blockIdx.y % p.Hh;
+  const int q = blockIdx.x * 128 + wave * 32 + li;
+  const bool qok = q < p.Nq;
+  const int sample = p.tok_idx ? b / p.nwin : b;
+  const int* tix = p.tok_idx ? p.tok_idx + (long)(b % p.nwin) * p.Nk : nullptr;
+  const int qrow = qok ? (tix ? tix[q] : q) : 0;
+
+  // Q^T fragments (B operand): lane (q, half) holds d = 16 s + 8 half + e
+  v8h qh[NS], ql[NS];
+  {
+    const float* qp = p.q + (long)sample * p.q_sB + (long)h * p.q_sH + (long)qrow * p.q_sT + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      float4 a = *reinterpret_cast<const float4*>(qp + 16 * s);
+      float4 c = *reinterpret_cast<const float4*>(qp + 16 * s + 4);
+      if (!qok) { a = make_float4(0.f, 0.f, 0.f, 0.f); c = a; }
+      const float qs = QSC;   // the softmax scale is applied to S in fp32, so this scaling stays an exact power of two
+      const float f[8] = {a.x * qs, a.y * qs, a.z * qs, a.w * qs, c.x * qs, c.y * qs, c.z * qs, c.w * qs};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        _Float16 hh, ll;
+        split_f16(f[e], hh, ll);
+        qh[s][e] = hh; ql[s][e] = ll;
+      }
+    }
+  }
+
+  v16f acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const float* kb = p.k + (long)sample * p.k_sB + (long)h * p.k_sH;
+  const float* vb = p.v + (long)sample * p.v_sB + (long)h * p.v_sH;
+
+  for (int k0 = 0; k0 < p.Nk; k0 += 32) {
+    __syncthreads();  // previous tile fully consumed
+    // K: thread -> (key row, 4 d): two 8-B plane writes
+    for (int idx = tid; idx < 32 * (D / 4); idx += 256) {
+      const int row = idx / (D / 4), c4 = idx - row * (D / 4);
+      const bool ok = k0 + row < p.Nk;
+      const int kr = ok ? (tix ? tix[k0 + row] : k0 + row) : 0;
+      float4 kv = *reinterpret_cast<const float4*>(kb + (long)kr * p.k_sT + c4 * 4);
+      kv = ok ? make_float4(kv.x * KSC, kv.y * KSC, kv.z * KSC, kv.w * KSC) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v4h hi, lo;
+      split4(kv, hi, lo);
+      *reinterpret_cast<v4h*>(&Kh[row * KP + c4 * 4]) = hi;
+      *reinterpret_cast<v4h*>(&Kl[row * KP + c4 * 4]) = lo;
+    }
+    // V, transposed: thread -> (key pair fastest, 4 d): 4-B writes Vt[d][2kp .. 2kp+1]
+    for (int idx = tid; idx < 16 * (DV / 4); idx += 256) {
+      const int kp = idx & 15, c4 = idx >> 4;
+      const bool ok0 = k0 + 2 * kp < p.Nk, ok1 = k0 + 2 * kp + 1 < p.Nk;
+      const int r0 = ok0 ? (tix ? tix[k0 + 2 * kp] : k0 + 2 * kp) : 0;
+      const int r1 = ok1 ? (tix ? tix[k0 + 2 * kp + 1] : k0 + 2 * kp + 1) : 0;
+      float4 v0 = *reinterpret_cast<const float4*>(vb + (long)r0 * p.v_sT + c4 * 4);
+      float4 v1 = *reinterpret_cast<const float4*>(vb + (long)r1 * p.v_sT + c4 * 4);
+      v0 = ok0 ? make_float4(v0.x * VSC, v0.y * VSC, v0.z * VSC, v0.w * VSC) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v1 = ok1 ? make_float4(v1.x * VSC, v1.y * VSC, v1.z * VSC, v1.w * VSC) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v4h h0, l0, h1, l1;
+      split4(v0, h0, l0);
+      split4(v1, h1, l1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+        v2h ph, pl;
+        ph[0] = h0[j]; ph[1] = h1[j];
+        pl[0] = l0[j]; pl[1] = l1[j];
+        *reinterpret_cast<v2h*>(&Vh[(c4 * 4 + j) * VP + 2 * kp]) = ph;
+        *reinterpret_cast<v2h*>(&Vl[(c4 * 4 + j) * VP + 2 * kp]) = pl;
+      }
+    }
+    __syncthreads();
+
+    // S^T = K . Q^T
+    v16f s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      const v8h kh = *reinterpret_cast<const v8h*>(&Kh[li * KP + 16 * st + 8 * lh]);
+      const v8h kl = *reinterpret_cast<const v8h*>(&Kl[li * KP + 16 * st + 8 * lh]);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], s, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] *= p.scale * (1.f / (QSC * KSC));
+
+    // online softmax over the 32 keys of this tile (16 in my registers, 16 in lane^32's)
+    float mt = -INFINITY;
+    if (p.biasT || p.maskT) {
+      const float* bt = p.biasT ? p.biasT + (long)h * p.Nk * p.Nq : nullptr;
+      const float* mk = p.maskT ? p.maskT + (long)(b % p.nmask) * p.Nk * p.Nq : nullptr;
+      float add[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const long o = (qok && key < p.Nk) ? (long)key * p.Nq + q : 0;
+        add[r] = (bt ? bt[o] : 0.f) + (mk ? mk[o] : 0.f);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] += add[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (key >= p.Nk) s[r] = -INFINITY;
+      mt = fmaxf(mt, s[r]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __expf(m_run - m_new);
+    float ps = 0.f;
+    v8h ph[2], pl[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __expf(s[r] - m_new);
+      ps += e;
+      _Float16 hi, lo;
+      split_f16(e * PSC, hi, lo);
+      ph[r >> 3][r & 7] = hi;
+      pl[r >> 3][r & 7] = lo;
+    }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
+
+    // O^T += V^T . P^T
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int d = t * 32 + li;
+        const v4h a0 = *reinterpret_cast<const v4h*>(&Vh[d * VP + 16 * s2 + 4 * lh]);
+        const v4h a1 = *reinterpret_cast<const v4h*>(&Vh[d * VP + 16 * s2 + 8 + 4 * lh]);
+        const v4h c0 = *reinterpret_cast<const v4h*>(&Vl[d * VP + 16 * s2 + 4 * lh]);
+        const v4h c1 = *reinterpret_cast<const v4h*>(&Vl[d * VP + 16 * s2 + 8 + 4 * lh]);
+        const v8h vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const v8h vl = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s2], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s2], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s2], acc[t], 0, 0, 0);
+      }
+  }
+
+  if (qok) {
+    const float inv = 1.f / (l_run * (PSC * VSC));
+    const long oo = (long)sample * p.o_sB + (long)h * p.o_sH + (long)qrow * p.o_sT;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 o4 = make_float4(acc[t][4 * g] * inv, acc[t][4 * g + 1] * inv, acc[t][4 * g + 2] * inv,
+                                acc[t][4 * g + 3] * inv);
+        const int dd = t * 32 + 8 * g + 4 * lh;
+        if (p.res) {
+          const float4 rr = *reinterpret_cast<const float4*>(p.res + oo + dd);
+          o4.x += rr.x; o4.y += rr.y; o4.z += rr.z; o4.w += rr.w;
+        }
+        *reinterpret_cast<float4*>(p.o + oo + dd) = o4;
+      }
+  }
+}
+
 // ------------------------------------------------------------------ MViTv2 decomposed relative positions
 // attn = (q*scale) k^T + q.Rh[hq,hk] + q.Rw[wq,wk] + q.Rt[tq,tk]   (backbones/MViT.py:905-997,1261-1290).
 // The three rank-structured terms are folded into the contraction itself: Q gets J = kH+kW+kT extra columns
@@ -323,6 +537,21 @@ extern "C" int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float*
   dim3 grid((unsigned)((d->Nq + 127) / 128), (unsigned)(d->B * d->Hh));
   hipStream_t s = (hipStream_t)stream;
   const int key = d->D * 1000 + d->Dv;
+  if (d->prec == MSPI_PREC_F16X3) {
+    switch (key) {
+      case 32032: hipLaunchKernelGGL((attn_f16x3_kernel<32, 32>), grid, dim3(256), 0, s, a); break;
+      case 64064: hipLaunchKernelGGL((attn_f16x3_kernel<64, 64>), grid, dim3(256), 0, s, a); break;
+      case 96096: hipLaunchKernelGGL((attn_f16x3_kernel<96, 96>), grid, dim3(256), 0, s, a); break;
+      case 128128: hipLaunchKernelGGL((attn_f16x3_kernel<128, 128>), grid, dim3(256), 0, s, a); break;
+      case 128096: hipLaunchKernelGGL((attn_f16x3_kernel<128, 96>), grid, dim3(256), 0, s, a); break;
+      case 160096: hipLaunchKernelGGL((attn_f16x3_kernel<160, 96>), grid, dim3(256), 0, s, a); break;
+      default:
+        set_error("mspi_attn_fwd: (D=%d, Dv=%d) not in {(32,32),(64,64),(96,96),(128,128),(128,96),(160,96)}", d->D, d->Dv);
+        return MSPI_EINVAL;
+    }
+    return check_launch("mspi_attn_fwd");
+  }
+  MSPI_REQUIRE(d->prec == MSPI_PREC_F32, "mspi_attn_fwd: prec = %d", d->prec);
   switch (key) {
     case 32032: hipLaunchKernelGGL((attn_kernel<32, 32>), grid, dim3(256), 0, s, a); break;
     case 64064: hipLaunchKernelGGL((attn_kernel<64, 64>), grid, dim3(256), 0, s, a); break;

@@ -54,6 +54,17 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
+// hi/lo f16 split of an fp32 value: x ~= hi + lo to 22 significand bits (the f16x3 operand form, conv_common.h).
+// x is pinned in a register first.  If the compiler may contract the multiply that PRODUCED x into the subtraction
+// below (fma(a, b, -hi)), hi is rounded from fl32(a*b) but lo is taken from the unrounded a*b, and in rare
+// double-rounding cases the pair is off by one f16 ulp of hi (2^-11): measured as 2e-5 outliers in 0.2 % of the rows
+// of the f16x3 attention when q was multiplied by a non-power-of-two scale right before its split.
+__device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
+  asm("" : "+v"(x));
+  hi = (_Float16)x;
+  lo = (_Float16)(x - (float)hi);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

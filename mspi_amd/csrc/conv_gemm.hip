@@ -218,15 +218,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
         v4h hi, lo;
-        hi[0] = (_Float16)ra[i].x; hi[1] = (_Float16)ra[i].y; hi[2] = (_Float16)ra[i].z; hi[3] = (_Float16)ra[i].w;
-        if (p.dbg & 1) {
-          lo = hi;
-        } else {
-          lo[0] = (_Float16)(ra[i].x - (float)hi[0]);
-          lo[1] = (_Float16)(ra[i].y - (float)hi[1]);
-          lo[2] = (_Float16)(ra[i].z - (float)hi[2]);
-          lo[3] = (_Float16)(ra[i].w - (float)hi[3]);
+        const float r4[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          _Float16 h, l;
+          split_f16(r4[e], h, l);
+          hi[e] = h; lo[e] = l;
         }
+        if (p.dbg & 1) lo = hi;
         *reinterpret_cast<v4h*>(&Ah[(rbase + RP * i) * LDH + kv * 4]) = hi;
         *reinterpret_cast<v4h*>(&Al[(rbase + RP * i) * LDH + kv * 4]) = lo;
       }

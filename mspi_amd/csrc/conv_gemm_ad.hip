@@ -174,8 +174,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p)
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      f.ah[e] = (_Float16)a8[e];
-      f.al[e] = (_Float16)(a8[e] - (float)f.ah[e]);
+      _Float16 h, l;
+      split_f16(a8[e], h, l);
+      f.ah[e] = h; f.al[e] = l;
     }
   };
   auto frag_mfma = [&](const Frag& f) {

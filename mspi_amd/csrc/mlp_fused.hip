@@ -122,9 +122,9 @@ __global__ __launch_bounds__(256, (C == 96 && TM == 1) ? (NS == 2 ? 3 : 2) : 1) 
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const _Float16 h = (_Float16)xr[t][ks][e];
-        xh[t][ks][e] = h;
-        xl[t][ks][e] = (_Float16)(xr[t][ks][e] - (float)h);
+        _Float16 h, l;
+        split_f16(xr[t][ks][e], h, l);
+        xh[t][ks][e] = h; xl[t][ks][e] = l;
       }
 
   v16f o[TM][CT];
@@ -184,9 +184,10 @@ __global__ __launch_bounds__(256, (C == 96 && TM == 1) ? (NS == 2 ? 3 : 2) : 1) 
       for (int i = 0; i < 16; ++i) {
         const float u = fmaf(h[t][i], p.inv_s1, bv[i]);
         const float v = 0.5f * u * (1.f + fast_erf(u * 0.70710678118654752440f));   // nn.GELU (erf form)
-        const _Float16 f = (_Float16)v;
+        _Float16 f, l;
+        split_f16(v, f, l);
         hh[t][i >> 3][i & 7] = f;
-        hl[t][i >> 3][i & 7] = (_Float16)(v - (float)f);
+        hl[t][i >> 3][i & 7] = l;
       }
     // ---- phase 2: Y^T += W2[:, chunk] . H
 #pragma unroll
@@ -299,10 +300,12 @@ struct RowGemmArgs {
   int rows_per_sample;
 };
 
+constexpr int RG_LDS = 72 * 1024;   // static: LDS budget of one workgroup (rowgemm_cps keeps cps * (SB + 128) below it)
+
 template <int KSB, bool GATE>
 __global__ __launch_bounds__(256, 2) void rowgemm_kernel(const RowGemmArgs p) {
   constexpr int SB = KSB * 2048;                 // bytes of one 32-column chunk: [ks][hi,lo][lane][8 halves]
-  extern __shared__ __attribute__((aligned(16))) unsigned char rg_smem[];   // cps * SB weights, then cps*32 bias floats
+  __shared__ __attribute__((aligned(16))) unsigned char rg_smem[RG_LDS];   // cps * SB weights, then cps*32 bias floats
   const int j0 = blockIdx.y * p.cps;
   const int nj = min(p.cps, p.nch - j0);
   float* bs = reinterpret_cast<float*>(rg_smem + (size_t)p.cps * SB);
@@ -351,9 +354,9 @@ __global__ __launch_bounds__(256, 2) void rowgemm_kernel(const RowGemmArgs p) {
   for (int ks = 0; ks < KSB; ++ks)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const _Float16 h = (_Float16)xr[ks][e];
-      xh[ks][e] = h;
-      xl[ks][e] = (_Float16)(xr[ks][e] - (float)h);
+      _Float16 h, l;
+      split_f16(xr[ks][e], h, l);
+      xh[ks][e] = h; xl[ks][e] = l;
     }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -400,20 +403,9 @@ __global__ __launch_bounds__(256, 2) void rowgemm_kernel(const RowGemmArgs p) {
 
 template <int KSB>
 static int launch_rowgemm(const RowGemmArgs& a, size_t lds, hipStream_t s) {
-  static bool attr_done = false;   // > 64 KB of dynamic LDS is an opt-in, once per instantiation
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<KSB, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<KSB, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) {
-      (void)hipGetLastError();
-      return -1;
-    }
-    attr_done = true;
-  }
   const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.nch + a.cps - 1) / a.cps));
-  if (a.gate) hipLaunchKernelGGL((rowgemm_kernel<KSB, true>), grid, dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((rowgemm_kernel<KSB, false>), grid, dim3(256), lds, s, a);
+  if (a.gate) hipLaunchKernelGGL((rowgemm_kernel<KSB, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((rowgemm_kernel<KSB, false>), grid, dim3(256), 0, s, a);
   return 0;
 }
 
@@ -434,7 +426,7 @@ static int rowgemm_cps(long M, int nch, int ksb) {
   if (row_tiles < 512) split = (int)((512 + row_tiles - 1) / row_tiles);
   if (split > nch) split = nch;
   int cps = (nch + split - 1) / split;
-  const int cap = (72 * 1024) / (ksb * 2048 + 128);   // <= 72 KB of LDS per workgroup
+  const int cap = RG_LDS / (ksb * 2048 + 128);        // the kernel's static LDS array
   if (cps > cap) cps = cap;
   return cps < 1 ? 1 : cps;
 }

@@ -313,6 +313,8 @@ def _f16_scale(w):
 
 def mlp_supported(c, hidden):
     """Shapes mspi_mlp_fwd covers (the rows stay in registers as MFMA fragments: C <= 192)."""
+    if _os.environ.get("MSPI_MLP_FUSED", "1") == "0":   # A/B switch
+        return False
     return DEFAULT_PREC == PREC_F16X3 and c in (96, 192) and hidden % 32 == 0 and hidden <= 1024
 
 
@@ -580,7 +582,7 @@ def attention(qkv, B, Ntok, heads, hd, scale, out=None, biasT=None, maskT=None, 
     d.q_sH = d.k_sH = d.v_sH = hd
     d.q_sT = d.k_sT = d.v_sT = qkv.ld
     d.o_sB, d.o_sH, d.o_sT = rows_per_sample * out.ld, hd, out.ld
-    d.scale = float(scale)
+    d.scale, d.prec = float(scale), DEFAULT_PREC
     base = qkv.ptr
     with _Timed("attention", 4.0 * B * heads * Ntok * Ntok * hd, 16.0 * B * Ntok * Cc, "B=%d h=%d N=%d d=%d" % (B, heads, Ntok, hd)):
         check(lib.mspi_attn_fwd(C.byref(d), base, base + 4 * Cc, base + 8 * Cc, None,
@@ -668,7 +670,7 @@ def mvit_attention(q, k, v, B, heads, hd, scale, q_thw, k_thw, Rh, Rw, Rt, out=N
     d.k_sB, d.k_sH, d.k_sT = heads * Nk * DA, Nk * DA, DA
     d.v_sB, d.v_sH, d.v_sT = Nk * v.ld, hd, v.ld
     d.o_sB, d.o_sH, d.o_sT = Nq * out.ld, hd, out.ld
-    d.scale = 1.0
+    d.scale, d.prec = 1.0, DEFAULT_PREC
     assert q.ld == out.ld and q.dense and out.dense   # residual pooling reads q with o's strides
     with _Timed("attention", 2.0 * B * heads * Nq * Nk * (DA + hd), 4.0 * B * heads * (Nq * (DA + 2 * hd) + Nk * (DA + hd)),
                 "B=%d h=%d Nq=%d Nk=%d d=%d+%d" % (B, heads, Nq, Nk, DA, hd)):

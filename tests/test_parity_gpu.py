@@ -172,3 +172,21 @@ def test_full_size_properties(dev):
     assert torch.equal(out, out2)                           # no atomics anywhere: bitwise reproducible
     sub, _ = m(clips[2:5], audio[2:5])
     assert (sub - out[2:5]).abs().max().item() < 1e-4
+
+
+def test_full_size_determinism_under_allocator_churn(dev):
+    """Bitwise run-to-run reproducibility of the three-stream forward while the caching allocator is churned between
+    runs (odd-sized buffers come and go, so every forward gets different blocks and different co-scheduling).  This is
+    the test that exposed the packed-fp32 (SLP) hazard: csrc/Makefile, -fno-slp-vectorize."""
+    from mspi_amd.model.model_utils import AudioVisualSaliencyModel
+    cfg = T.make_cfg("x3dl", num_aud_tokens=90)
+    m = T.seeded(lambda: AudioVisualSaliencyModel(cfg), 0).to(dev)
+    clips, audio = T.synth_inputs(8, 16, 224, 224, Wa=300, seed=1, device=dev)
+    ref = m(clips, audio)[0].clone()
+    junk = []
+    for i in range(25):
+        junk.append(torch.full((1 + (i * 7919) % 5000, 1031), float(i), device=dev))
+        if len(junk) > 3:
+            junk.pop(0)
+        out = m(clips, audio)[0]
+        assert torch.equal(out, ref), "forward %d differs from the first one (max %.3e)" % (i, (out - ref).abs().max().item())

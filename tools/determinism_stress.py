@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Run the full-size forward repeatedly, with allocator churn between runs, and count outputs that differ bitwise from the
+first one.  This is how the packed-fp32 (SLP) hazard was found: with v_pk_*_f32 code in the element-wise kernels about a
+third of the runs differed whenever the image branch ran on a side stream beside MFMA-heavy kernels."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mspi_amd import engine as E, testing as T
+from mspi_amd.model.model_utils import AudioVisualSaliencyModel
+dev = torch.device("cuda")
+name = sys.argv[1] if len(sys.argv) > 1 else "x3dl"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+t_tok = {"x3dl": 16, "slowfast4x16": 4}.get(name, 8)
+cfg = T.make_cfg(name, num_aud_tokens=90, num_vis_tokens=t_tok * 49)
+so, sys.stdout = sys.stdout, open(os.devnull, "w")
+m = T.seeded(lambda: AudioVisualSaliencyModel(cfg), 0).to(dev)
+sys.stdout = so
+clips, audio = T.synth_inputs(8, 16, 224, 224, Wa=300, seed=1, device=dev)
+if os.environ.get("STRESS_AUTOTUNE"):
+    E.autotune(True)
+ref, _ = m(clips, audio)
+ref = ref.clone()
+junk = []
+bad = 0
+for i in range(reps):
+    # churn the allocator like a test suite does: odd-sized garbage buffers come and go
+    junk.append(torch.full((1 + (i * 7919) % 5000, 1031), float(i), device=dev))
+    if len(junk) > 3:
+        junk.pop(0)
+    out, _ = m(clips, audio)
+    if not torch.equal(out, ref):
+        bad += 1
+        d = (out - ref).abs()
+        print("run %d differs: max %.3e, %d elements, samples %s" % (i, d.max().item(), (d > 0).sum().item(),
+              sorted(set((d > 0).nonzero()[:, 0].tolist()))), flush=True)
+print("%s: %d of %d runs differ" % (name, bad, reps))

@@ -15,6 +15,9 @@ SHAPES = {   # name: (N,T,H,W,Cin, Cout, k, stride, pad)
     "cnx1_fc1": (128, 1, 56, 56, 96, 384, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     "cnx1_fc2": (128, 1, 56, 56, 384, 96, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     "readout333": (8, 4, 56, 56, 192, 192, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    "cnx4_fc1": (128, 1, 7, 7, 768, 3072, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    "cnx4_fc2": (128, 1, 7, 7, 3072, 768, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    "sync_fc1": (8, 874, 1, 1, 512, 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     "x3d_a": (8, 16, 28, 28, 48, 108, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     "sa333": (8, 4, 14, 14, 512, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
 }
@@ -30,19 +33,24 @@ def main():
         x = E.alloc(N, T, H, W, Ci, dev)
         x.buf.copy_(torch.randn(x.buf.numel(), generator=g))
         w = torch.randn(Co, Ci, *k, generator=g) / (Ci * k[0] * k[1] * k[2]) ** 0.5
-        for prec in (E.PREC_F16X3, E.PREC_F32):
+        tiles = [int(t) for t in os.environ["MSPI_PROBE_TILES"].split(",")] if "MSPI_PROBE_TILES" in os.environ else [None]
+        for prec, tile in [(E.PREC_F16X3, t) for t in tiles] + ([] if tiles != [None] else [(E.PREC_F32, None)]):
             pk = E.pack_conv(w, None, None, s, p, device=dev, prec=prec)
-            out = E.conv(x, pk)
+            try:
+                out = E.conv(x, pk, tile=tile)
+            except Exception as e:
+                print("%-12s tile %s: %s" % (n, tile, str(e)[:60]))
+                continue
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                E.conv(x, pk, out=out)
+                E.conv(x, pk, out=out, tile=tile)
             e1.record()
             torch.cuda.synchronize()
             us = 1e3 * e0.elapsed_time(e1) / reps
             fl = 2.0 * out.M * Ci * k[0] * k[1] * k[2] * Co
-            print("%-12s %-6s %9.1f us  %7.1f TFLOP/s" % (n, "f16x3" if prec else "f32", us, fl / us / 1e6), flush=True)
+            print("%-12s %-6s tile %-4s %9.1f us  %7.1f TFLOP/s" % (n, "f16x3" if prec else "f32", tile, us, fl / us / 1e6), flush=True)
 
 
 if __name__ == "__main__":
