@@ -28,6 +28,17 @@ def profiler_name(k):
     m = re.match(r"conv_gemm_dma_kernel<(\d+),", k)
     if m:
         return "conv_gemm<128,%s,dma,f16x3>" % m.group(1)
+    m = re.match(r"rowgemm_kernel<(\d+),", k)
+    if m:
+        return "rowgemm<%s,f16x3>" % m.group(1)
+    if k.startswith("mlp_fused_kernel"):
+        return "mlp_fused"
+    if k.startswith("attn_f16x3_kernel") or k.startswith("attn_kernel"):
+        return "attention"
+    if k.startswith("dw_strip_kernel") or k.startswith("dw_tile_kernel") or k.startswith("dw_kernel<false"):
+        return "dwconv"
+    if k.startswith("layernorm_kernel"):
+        return "layernorm"
     return None
 
 
