@@ -310,19 +310,34 @@ class _Fork:
             d["_side_streams"] = [torch.cuda.Stream(device) for _ in range(2)]
         self.side = d["_side_streams"]
         self.used = []
+        self.kept = []
 
     def __enter__(self):
         self.start = torch.cuda.Event()
         self.start.record(self.main)
         return self
 
-    def branch(self, i):
+    def branch(self, i, refork=False):
+        """Context manager that runs its body on side stream i.  refork=True: the branch starts from the main
+        stream's CURRENT position (a second use of the stream, after an earlier join), not from the fork point."""
         if not self.ENABLED:
             return torch.cuda.stream(self.main)
         s = self.side[i]
-        s.wait_event(self.start)
-        self.used.append(s)
+        if refork:
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+            s.wait_event(ev)
+        else:
+            s.wait_event(self.start)
+        if s not in self.used:
+            self.used.append(s)
         return torch.cuda.stream(s)
+
+    def keep(self, *objs):
+        """Hold references until the join at exit: memory allocated on the main stream that a side-stream kernel reads
+        would otherwise go back to the caching allocator when its last Python reference dies, and be handed to a later
+        main-stream kernel while the side stream has not run yet."""
+        self.kept.extend(objs)
 
     def join(self, i):
         """Make the main stream wait for branch i now (its results are needed before the others finish)."""
@@ -339,6 +354,7 @@ class _Fork:
             ev.record(s)
             self.main.wait_event(ev)
         self.used = []
+        self.kept = []
         return False
 
 
@@ -559,24 +575,27 @@ class AudioVisualSaliencyModel(_SaliencyBase):
             v1, v2, v3, v4 = self.visnet.forward_cl(self._pack_clips(clips))
             cat, s0, s1, s2 = self._laterals_012(pk, v1, v2, v3)
             fk.join(1)
-            s3, loss = self._sync_and_lateral3(pk, v4, aud)
+            s3, loss = self._sync_and_lateral3(pk, v4, aud, fk)
         return self._fuse_readout(pk, cat, s0, s1, s2, s3, masks, pm), loss
 
-    def _sync_and_lateral3(self, pk, v4, aud):
+    def _sync_and_lateral3(self, pk, v4, aud, fk):
         B, dev = v4.N, v4.buf.device
         x = self.aud_vis_sync_block.run(v4, aud)
         Rv = v4.T * v4.H * v4.W
         vis_fea = x.tokens(0, v4.T, v4.H, v4.W)
         aud_fea = x.tokens(Rv, aud.T, aud.H, aud.W)
-        # contrastive branch: its value is the second return (model/model_utils.py:545-552)
-        pooled = torch.empty(2, B, 512, dtype=torch.float32, device=dev)
-        E.mean_rows(vis_fea, B, Rv, pooled[0])
-        E.mean_rows(aud_fea, B, aud.T * aud.H * aud.W, pooled[1])
-        vis_emb, vis_pred = self._embed(pk["vis"], E.from_rows(pooled[0]))
-        aud_emb, aud_pred = self._embed(pk["aud"], E.from_rows(pooled[1]))
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
-        E.neg_cosine(vis_pred, aud_emb, loss, 0.5, False)
-        E.neg_cosine(aud_pred, vis_emb, loss, 0.5, True)
+        # Contrastive branch: its value is the second return (model/model_utils.py:545-552), nothing on the map's path
+        # reads it -- a dozen tiny launches (M = B rows) that go to the audio branch's now idle stream.
+        fk.keep(x)   # main-stream memory read by the side stream: must not return to the allocator before the join
+        with fk.branch(1, refork=True):
+            pooled = torch.empty(2, B, 512, dtype=torch.float32, device=dev)
+            E.mean_rows(vis_fea, B, Rv, pooled[0])
+            E.mean_rows(aud_fea, B, aud.T * aud.H * aud.W, pooled[1])
+            vis_emb, vis_pred = self._embed(pk["vis"], E.from_rows(pooled[0]))
+            aud_emb, aud_pred = self._embed(pk["aud"], E.from_rows(pooled[1]))
+            loss = torch.empty(1, dtype=torch.float32, device=dev)
+            E.neg_cosine(vis_pred, aud_emb, loss, 0.5, False)
+            E.neg_cosine(aud_pred, vis_emb, loss, 0.5, True)
         return self._lateral(pk, 3, [v4, vis_fea]), loss[0]
 
 
