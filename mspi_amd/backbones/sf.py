@@ -116,10 +116,14 @@ class SlowFast(HipModule):
         return [f.as_ncdhw() for f in self.forward_cl(x)]
 
     def load_weight(self, path):
-        """The released SLOWFAST_4x16_R50.pkl is a caffe2 pickle that upstream converts by name
-        (SlowFast/slowfast/utils/checkpoint.py:191-...); that converter is a 'next' row.
+        """The released SLOWFAST_4x16_R50.pkl is a caffe2 pickle that upstream converts by blob name
+        (backbones/sf.py:387-388 -> SlowFast/slowfast/utils/checkpoint.py:226-292): mspi_amd/weights.py.
         PyTorch-format checkpoints ({'model_state': ...} or a bare state dict) load directly."""
         if str(path).endswith(".pkl"):
-            raise NotImplementedError("caffe2 .pkl conversion is not part of the hot path (SURVEY.md section 8f, rank 1)")
+            from ..weights import load_caffe2_pkl
+            rep = load_caffe2_pkl(path, self)
+            print("SlowFast caffe2 weights: %d tensors loaded, %d model tensors not covered, %d blobs unmatched" % (
+                len(rep["loaded"]), len(rep["missing"]), len(rep["unmatched"])))
+            return rep
         ck = torch.load(path, map_location="cpu")
         self.load_state_dict(ck.get("model_state", ck), strict=False)

@@ -259,6 +259,49 @@ def case_vis_x3dl_64():
     _model_case("x3dl", "VisualSaliencyModel", 64, 2, 111, 0, "vis_x3dl_64")
 
 
+def c2_name_corpus():
+    """caffe2 blob names of the ResNet / SlowFast / X3D / non-local model-zoo families (R50 depths), plus optimizer
+    blobs and a few names that match no rule -- the input side of tests/golden/c2_names.json."""
+    names = ["lr", "model_iter", "pred_w", "pred_b", "conv1_xy_w", "conv1_xy_w_momentum", "conv_5_w", "conv_5_bn_s",
+             "lin_5_w", "lin_5_b", "res2_0_branch2b_bn_fc1_w", "res2_0_branch2b_bn_fc2_b", "unrelated_blob", "w", "foo_bar_w"]
+    bn = ("s", "b", "rm", "riv")
+    for pre in ("", "t_"):
+        names += [pre + "conv1_w", pre + "conv1_w_momentum", pre + "res_conv1_w"] + [pre + "res_conv1_bn_" + f for f in bn]
+        for stage, depth in ((2, 3), (3, 4), (4, 6), (5, 3)):
+            for blk in range(depth):
+                for letter in "abc":
+                    base = "%sres%d_%d_branch2%s" % (pre, stage, blk, letter)
+                    names += [base + "_w", base + "_w_momentum"] + [base + "_bn_" + f for f in bn]
+                if blk == 0:
+                    base = "%sres%d_0_branch1" % (pre, stage)
+                    names += [base + "_w"] + [base + "_bn_" + f for f in bn]
+    names += ["t_pool1_subsample_w"] + ["t_pool1_subsample_bn_" + f for f in bn]
+    for stage, last in ((2, 2), (3, 3), (4, 5)):
+        base = "t_res%d_%d_branch2c_bn_subsample" % (stage, last)
+        names += [base + "_w"] + [base + "_bn_" + f for f in bn]
+    for stage, blk in ((3, 1), (3, 3), (4, 1), (4, 5)):
+        for part in ("theta", "g", "phi", "out"):
+            names += ["nonlocal_conv%d_%d_%s_w" % (stage, blk, part), "nonlocal_conv%d_%d_%s_b" % (stage, blk, part)]
+        names += ["nonlocal_conv%d_%d_bn_%s" % (stage, blk, f) for f in bn]
+    return names
+
+
+def case_c2_names():
+    """Blob-name translation of the reference (SlowFast/slowfast/utils/c2_model_loading.py:9-120) on the corpus above."""
+    import json
+    cwd = os.getcwd()
+    rh.enter_reference()
+    from SlowFast.slowfast.utils.c2_model_loading import get_name_convert_func
+    os.chdir(cwd)
+    conv = get_name_convert_func()
+    names = c2_name_corpus()
+    out = {n: conv(n) for n in names}
+    path = os.path.join(GOLD, "c2_names.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("  wrote %s (%d names)" % (path, len(out)))
+
+
 CASES = {k[5:]: v for k, v in list(globals().items()) if k.startswith("case_")}
 
 if __name__ == "__main__":
