@@ -280,6 +280,13 @@ int mspi_rowgemm_supported(int32_t K, int32_t N);
 int mspi_rowgemm_fwd(const MspiRowGemmDesc* d, const void* x, const void* w_packed, const void* bias, const void* res,
                      const void* gate, void* y, mspi_stream_t stream);
 
+/* Saliency metrics (utils/compute_saliency_metrics.py:9-108; the terms of utils/loss.py:26-49): per sample n,
+ * out[n] = { KL(gt || pred), CC(pred, gt), SIM(pred, gt), NSS(pred, fix) } over the L = H*W values of each map.
+ * pred is the predicted map (pred_is_log: the model's log-probability map, exponentiated on the fly), gt the
+ * ground-truth density, fix the binary fixation map (NULL: NSS is written as 0).  Batch means are the caller's. */
+int mspi_saliency_metrics(const float* pred, const float* gt, const float* fix, float* out /*[N][4]*/, int32_t N, int32_t L,
+                          int32_t pred_is_log, mspi_stream_t stream);
+
 /* y = a + b over n floats (plain residual add where no producer can fuse it). */
 int mspi_add(const float* a, const float* b, float* y, int64_t n, mspi_stream_t stream);
 

@@ -108,6 +108,7 @@ _SIGNATURES = {
     "mspi_mean_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mspi_neg_cosine": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P]),
     "mspi_add": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "mspi_saliency_metrics": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mspi_rowgemm_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "mspi_rowgemm_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "mspi_rowgemm_fwd": (C.c_int, [C.POINTER(RowGemmDesc), _P, _P, _P, _P, _P, _P, _P]),

@@ -302,6 +302,27 @@ def case_c2_names():
     print("  wrote %s (%d names)" % (path, len(out)))
 
 
+def case_saliency_metrics(seed=0):
+    """utils/compute_saliency_metrics.py kldiv / cc / similarity / nss (batch means) and utils/loss.py's combination on
+    seeded maps; `cv2` (imported at the top of that file, used only by auc_judd's resize) is an inert stub here."""
+    import types
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    cwd = os.getcwd()
+    rh.enter_reference()
+    from utils import compute_saliency_metrics as M
+    os.chdir(cwd)
+    g = torch.Generator().manual_seed(seed)
+    B, H, W = 3, 24, 40
+    logits = torch.rand(B, H, W, generator=g) * 6
+    pred = torch.softmax(logits.flatten(1), 1).view(B, H, W)               # a probability map, like exp(model output)
+    gt = torch.rand(B, H, W, generator=g) ** 4                             # peaky density
+    fix = (torch.rand(B, H, W, generator=g) > 0.97).float()
+    ref = torch.stack([M.kldiv(pred, gt), M.cc(pred, gt), M.similarity(pred, gt), M.nss(pred, fix)])
+    ora = R.saliency_metrics(pred, gt, fix)
+    _check_restatement("saliency_metrics", [ref], [ora.mean(0)], tol=1e-6)
+    _save("saliency_metrics", pred=pred, gt=gt, fix=fix, ref_means=ref, per_sample=ora)
+
+
 CASES = {k[5:]: v for k, v in list(globals().items()) if k.startswith("case_")}
 
 if __name__ == "__main__":

@@ -557,3 +557,26 @@ def postprocess_u8(logmap, out_hw):
     x = F.interpolate(x, size=out_hw, mode="bilinear", align_corners=False)[0, 0]
     x = (x - x.min()) / (x.max() - x.min())
     return torch.round(x * 255).to(torch.uint8)
+
+
+# ----------------------------------------------------------------------------- saliency metrics
+def saliency_metrics(pred, gt, fix=None):
+    """Per-sample (KL, CC, SIM, NSS) of utils/compute_saliency_metrics.py:9-108 on [B,H,W] maps, [B,4] float tensor
+    (the reference returns the batch mean of each column)."""
+    B = pred.shape[0]
+    s, g = pred.reshape(B, -1).float(), gt.reshape(B, -1).float()
+    eps = 2.2204e-16
+    sp, gp = s / s.sum(1, keepdim=True), g / g.sum(1, keepdim=True)
+    kl = (gp * torch.log(eps + gp / (sp + eps))).sum(1)                                    # kldiv :9-31
+    sz = (s - s.mean(1, keepdim=True)) / s.std(1, keepdim=True)
+    gz = (g - g.mean(1, keepdim=True)) / g.std(1, keepdim=True)
+    cc = (sz * gz).sum(1) / torch.sqrt((sz * sz).sum(1) * (gz * gz).sum(1))                # cc :73-90
+    sn = (s - s.min(1, keepdim=True)[0]) / (s.max(1, keepdim=True)[0] - s.min(1, keepdim=True)[0])
+    gn = (g - g.min(1, keepdim=True)[0]) / (g.max(1, keepdim=True)[0] - g.min(1, keepdim=True)[0])
+    sim = torch.min(sn / sn.sum(1, keepdim=True), gn / gn.sum(1, keepdim=True)).sum(1)     # similarity :46-70
+    if fix is None:
+        ns = torch.zeros(B)
+    else:
+        f = fix.reshape(B, -1).float()
+        ns = (((s - s.mean(1, keepdim=True)) / (s.std(1, keepdim=True) + eps)) * f).sum(1) / f.sum(1)   # nss :93-107
+    return torch.stack([kl, cc, sim, ns], 1)
