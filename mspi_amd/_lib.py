@@ -132,6 +132,11 @@ def load():
         raise MspiError(
             "libmspi_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(mspi_amd has no CPU fallback)" % LIB_PATH)
+    # One HIP runtime per process: the library is linked against libamdhip64.so.7 and PyTorch ships its own copy under
+    # the same SONAME.  Whichever is loaded first serves both; if this library came first, torch would later find the
+    # system runtime already resident beside its bundled HSA stack and every launch from here fails with "no
+    # ROCm-capable device is detected" (seen when build() loaded the library before anything had imported torch).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
