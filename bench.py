@@ -44,6 +44,8 @@ def parse():
                     "kernel instantiations per conv shape during the first, untimed forward -- cudnn.benchmark's role upstream)")
     ap.add_argument("--tune-cache", default=None, help="JSON file of tile choices: loaded when it exists (no tuning launches, "
                     "e.g. under rocprofv3), otherwise written after the first forward")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1: nccl (= RCCL over xGMI); gloo only "
+                    "to rehearse the multi-rank control flow on a box where the ranks have to share one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel timing table to stderr")
@@ -97,10 +99,15 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if os.environ.get("MSPI_BENCH_SHARE_GPU"):     # rehearsal of the N>1 control flow on a one-GPU box
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from mspi_amd import engine as E
     from mspi_amd import testing as T
@@ -142,7 +149,8 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: the capture must not trip over CUDA calls of other threads (the RCCL watchdog polls events)
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             out, loss = model(clips, audio)
 
     def step():
@@ -152,7 +160,10 @@ def main():
         else:
             o, _ = model(clips, audio)
         if world > 1:                             # map collection over xGMI
-            dist.gather(o, gathered, dst=0)
+            if args.backend == "nccl":
+                dist.gather(o, gathered, dst=0)
+            else:                                 # gloo has no device gather: rehearsal only
+                dist.gather(o.cpu(), [g.cpu() for g in gathered] if gathered is not None else None, dst=0)
         return o
 
     for _ in range(args.warmup):
