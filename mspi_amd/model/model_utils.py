@@ -449,6 +449,25 @@ class _SaliencyBase(HipModule):
         s0 = self._lateral(pk, 0, [v1], out=cat.slice(0, 192))
         return cat, s0, self._lateral(pk, 1, [v2]), self._lateral(pk, 2, [v3])
 
+    @torch.no_grad()
+    def encode_frames(self, frames):
+        """Per-frame half of the image branch (ConvNeXt-T + the two smoothing convs, model/model_utils.py:357-385) for
+        frames [N,3,H,W]: (f1 [N,h,w,96], f0 [N,h/2,w/2,320]) dense fp32 tensors.  Nothing in it mixes frames, so a
+        frame's features are the same in every window that contains it: cache them and pass them to
+        forward(..., frame_feats=...) -- the clip loop of inference.py does."""
+        self._check_eval()
+        o1, o0 = self.image_encoder.run(frames.float()[:, :, None])
+        return (o1.buf.view(o1.N, o1.H, o1.W, o1.ld)[..., :o1.C], o0.buf.view(o0.N, o0.H, o0.W, o0.ld)[..., :o0.C])
+
+    @staticmethod
+    def _wrap_frame_feats(frame_feats):
+        outs = []
+        for f in frame_feats:
+            f = f.float().contiguous()
+            n, h, w, c = f.shape
+            outs.append(E.CL(f.view(-1), 0, n, 1, h, w, c, c))
+        return outs
+
     def _premask(self, pk, masks):
         """The three SA modules' first convs (same input) as one 512->96 conv."""
         return E.conv(masks, pk["sa_cat"])
@@ -556,7 +575,9 @@ class AudioVisualSaliencyModel(_SaliencyBase):
         return emb, E.conv(y, p[4])
 
     @torch.no_grad()
-    def forward(self, clips, audios):
+    def forward(self, clips, audios, frame_feats=None):
+        """frame_feats: optional (f1 [B*T,h,w,96], f0 [B*T,h/2,w/2,320]) from encode_frames() for the clips' frames in
+        (b t) order -- the image branch then starts at the adapter (sliding-window inference re-uses 15 of 16 frames)."""
         self._check_eval()
         pk = self.pk
         clips = clips.float()
@@ -567,7 +588,7 @@ class AudioVisualSaliencyModel(_SaliencyBase):
         # capture records them as parallel branches.
         with _Fork(self, dev) as fk:
             with fk.branch(0):
-                o1, o0 = self.image_encoder.run(clips)
+                o1, o0 = self.image_encoder.run(clips) if frame_feats is None else self._wrap_frame_feats(frame_feats)
                 masks = self.adapter.run(o1, o0)
                 pm = self._premask(pk, masks)
             with fk.branch(1):
@@ -622,13 +643,13 @@ class VisualSaliencyModel(_SaliencyBase):
         return self._pack_decoder(split=None)
 
     @torch.no_grad()
-    def forward(self, clips):
+    def forward(self, clips, frame_feats=None):
         self._check_eval()
         pk = self.pk
         clips = clips.float()
         with _Fork(self, clips.device) as fk:
             with fk.branch(0):
-                o1, o0 = self.image_encoder.run(clips)
+                o1, o0 = self.image_encoder.run(clips) if frame_feats is None else self._wrap_frame_feats(frame_feats)
                 masks = self.adapter.run(o1, o0)
                 pm = self._premask(pk, masks)
             v1, v2, v3, v4 = self.visnet.forward_cl(self._pack_clips(clips))

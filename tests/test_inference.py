@@ -109,3 +109,42 @@ def test_clip_loop_end_to_end(dev, tmp_path):
     assert np.abs(got - want).max() <= 2
     img = np.asarray(Image.open(os.path.join(args.save_path, "clip1", "img_00020.jpg")))
     assert img.shape == (480, 640) and np.abs(img.astype(int) - want).mean() < 3.0
+
+
+@pytest.mark.gpu
+def test_frame_feature_cache(dev, tmp_path):
+    """per-frame image-branch features cached across overlapping windows.  (a) forward with
+    frame_feats == forward without, for two windows that share 15 frames and a time-reversed one; (b) the clip loop with
+    the cache writes the same maps as the loop that re-encodes every window."""
+    from PIL import Image
+    from mspi_amd import inference as I
+    from mspi_amd import testing as T
+    root = str(tmp_path / "data")
+    _make_dataset(root, n_frames=36)
+    res = (64, 96)
+    I.device = dev
+    I._RESOLUTION[:] = list(res)
+    model = I.build_model("x3dl", res)
+    T.randomize_(model.cpu(), 0)
+    model = model.to(dev).eval()
+    frames = torch.stack([I.torch_transform(os.path.join(root, "video_frames", "TOY", "clip1", "img_%05d.jpg" % (i + 1)))[0]
+                          for i in range(17)]).to(dev)                                        # [17,3,H,W]
+    wav = os.path.join(root, "video_audio", "TOY", "clip1", "clip1.wav")
+    idx = [list(range(0, 16)), list(range(1, 17)), list(range(15, -1, -1))]
+    clips = torch.stack([frames[i].permute(1, 0, 2, 3) for i in idx])                         # [3,3,16,H,W]
+    aud = torch.stack([I.get_audio_feature(wav, 0, "25"), I.get_audio_feature(wav, 1, "25"),
+                       I.get_audio_feature(wav, 0, "25", mode=True)]).to(dev)
+    f1, f0 = model.encode_frames(frames)
+    flat = [j for w in idx for j in w]
+    a = model(clips, aud)[0]
+    b = model(clips, aud, frame_feats=(f1[flat], f0[flat]))[0]
+    assert (a - b).abs().max().item() < 1e-5
+    out = {}
+    for tag, cache in (("cached", True), ("plain", False)):
+        args = types.SimpleNamespace(clip_size=16, dataset="TOY", split=2, path_data=root, save_path=str(tmp_path / tag),
+                                     use_sound=True, batch=4, cache_frames=cache)
+        I.inference_dataset(model, args)
+        names = sorted(os.listdir(os.path.join(args.save_path, "clip1")))
+        assert len(names) == 36
+        out[tag] = np.stack([np.asarray(Image.open(os.path.join(args.save_path, "clip1", n))).astype(int) for n in names])
+    assert np.abs(out["cached"] - out["plain"]).max() <= 1
