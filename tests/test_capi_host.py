@@ -48,6 +48,32 @@ def test_descriptor_validation_without_gpu():
     a.D = a.Dv = 48
     assert lib.mspi_attn_fwd(ctypes.byref(a), p, p, p, None, None, None, None, p, None) == -1
     assert b"not in" in lib.mspi_last_error()
+    a.D = a.Dv = 64
+    a.prec = 7                                   # neither MSPI_PREC_F32 nor MSPI_PREC_F16X3
+    assert lib.mspi_attn_fwd(ctypes.byref(a), p, p, p, None, None, None, None, p, None) == -1
+    assert b"prec" in lib.mspi_last_error()
+    # fused MLP: only C in {96, 192}, GELU between the layers, LayerNorm needs its parameters
+    m = _lib.MlpDesc()
+    m.M, m.C, m.hidden, m.ldx, m.ldy, m.act, m.w1_scale, m.w2_scale = 10, 128, 512, 128, 128, 2, 1.0, 1.0
+    assert lib.mspi_mlp_fwd(ctypes.byref(m), p, None, None, p, p, p, None, p, None) == -1
+    assert b"not supported" in lib.mspi_last_error()
+    m.C, m.hidden, m.ldx, m.ldy, m.ln = 96, 384, 96, 96, 1
+    assert lib.mspi_mlp_fwd(ctypes.byref(m), p, None, None, p, p, p, None, p, None) == -1
+    assert b"gamma" in lib.mspi_last_error()
+    m.ln, m.act = 0, 1
+    assert lib.mspi_mlp_fwd(ctypes.byref(m), p, None, None, p, p, p, None, p, None) == -1
+    assert b"GELU" in lib.mspi_last_error()
+    assert lib.mspi_mlp_packed_bytes(96, 384) == 12 * (6 * 2048 + 2 * 3 * 2048)
+    # thin GEMM: K <= 224 storage columns, multiples of 4
+    assert lib.mspi_rowgemm_supported(216, 96) == 1 and lib.mspi_rowgemm_supported(416, 96) == 0
+    assert lib.mspi_rowgemm_packed_bytes(96, 216) == 7 * 8 * 2048
+    r = _lib.RowGemmDesc()
+    r.M, r.K, r.N, r.ldx, r.ldy, r.w_scale = 5, 416, 96, 416, 96, 1.0
+    assert lib.mspi_rowgemm_fwd(ctypes.byref(r), p, p, None, None, None, p, None) == -1
+    assert b"outside" in lib.mspi_last_error()
+    r.K, r.ldx = 54, 56
+    assert lib.mspi_rowgemm_fwd(ctypes.byref(r), p, p, None, None, None, p, None) == -1      # K not a multiple of 4
+    assert lib.mspi_saliency_metrics(p, p, None, p, 0, 100, 0, None) == -1                     # empty batch
 
 
 def test_missing_library_is_loud(monkeypatch, tmp_path):
