@@ -52,12 +52,35 @@ class ResNetBasicStem(HipModule):
         self.relu = nn.ReLU(True)
         self.pool_layer = nn.MaxPool3d(kernel_size=[1, 3, 3], stride=[1, 2, 2], padding=[0, 1, 1])
 
+    WIDE = 4   # output positions along W computed by one GEMM column group in the narrow-stem form
+
     def _pack(self):
         c = self.conv
-        return E.pack_conv(c.weight, None, self.bn, c.stride, c.padding, E.ACT_RELU)
+        pk = {"conv": E.pack_conv(c.weight, None, self.bn, c.stride, c.padding, E.ACT_RELU), "wide": None}
+        kw, sw, pw = c.kernel_size[2], c.stride[2], c.padding[2]
+        if c.out_channels <= 8 and sw == 2 and kw % 2 == 1 and pw == kw // 2:
+            # Narrow stem (SlowFast's fast pathway: 3 -> 8 channels, (5,7,7)/(1,2,2), 9.6 % of the slowfast4x16 step): as
+            # a GEMM it has N = 8, a quarter of one 32-wide MFMA tile.  Four neighbouring outputs along W read one
+            # 13-wide window (7 + 3*2), so the SAME conv is a (5,7,13)/(1,2,8) conv with 4*8 = 32 output channels whose
+            # weights are the original taps shifted by 2j for output j (zeros elsewhere): the channels-last result
+            # [.., W/8, (j, co)] IS [.., W/2, co].  2.15x fewer MFMAs and gathered activations per output.
+            w, b = E.fold_bn(c.weight, None, self.bn)
+            G, co = self.WIDE, c.out_channels
+            wide = torch.zeros(G * co, w.shape[1], w.shape[2], w.shape[3], kw + (G - 1) * sw, device=w.device)
+            for j in range(G):
+                wide[j * co:(j + 1) * co, :, :, :, j * sw:j * sw + kw] = w
+            pk["wide"] = E.pack_conv(wide, b.repeat(G), None, (c.stride[0], c.stride[1], G * sw), c.padding, E.ACT_RELU)
+        return pk
 
     def run(self, x, out=None):
-        return E.maxpool(E.conv(x, self.pk), (1, 3, 3), (1, 2, 2), (0, 1, 1), out=out)
+        pk = self.pk
+        W = x.W if isinstance(x, E.CL) else x.shape[-1]
+        if pk["wide"] is not None and W % (2 * self.WIDE) == 0:
+            y = E.conv(x, pk["wide"])                                     # [N,T,Ho,Wo/4, 4*Cout]
+            y = E.CL(y.buf, y.off, y.N, y.T, y.H, y.W * self.WIDE, self.conv.out_channels, self.conv.out_channels)
+        else:
+            y = E.conv(x, pk["conv"])
+        return E.maxpool(y, (1, 3, 3), (1, 2, 2), (0, 1, 1), out=out)
 
 
 class VideoModelStem(HipModule):

@@ -411,6 +411,8 @@ def conv(x, pk, out=None, res=None, gate=None, act=None, tile=None):
         xptr, dev = x.data_ptr(), x.device
     if Cin != pk.cin_s:
         raise MspiError("conv: input has %d stored channels, weights were packed for %d" % (Cin, pk.cin_s))
+    if pk.w.device != dev:   # a host pointer handed to a kernel is a GPU memory fault, not an exception
+        raise MspiError("conv: packed weights live on %s, the input on %s" % (pk.w.device, dev))
     To, Ho, Wo = _out_extent(T, H, W, pk.k, pk.stride, pk.pad)
     if out is None:
         out = alloc(N, To, Ho, Wo, pk.cout, dev)
@@ -502,6 +504,8 @@ def dwconv(x, pk, out=None, pool=False, act=None):
     _need_gpu(x.buf)
     if x.Cs != pk.c_s:
         raise MspiError("dwconv: input has %d channels, weights packed for %d" % (x.C, pk.c_s))
+    if pk.w.device != x.buf.device:
+        raise MspiError("dwconv: packed weights live on %s, the input on %s" % (pk.w.device, x.buf.device))
     To, Ho, Wo = _out_extent(x.T, x.H, x.W, pk.k, pk.stride, pk.pad)
     if out is None:
         out = alloc(x.N, To, Ho, Wo, x.C, x.buf.device)
@@ -598,6 +602,8 @@ def mlp(x, pk, res=None, ln=None, eps=1e-6, out=None):
     _need_gpu(x.buf)
     if x.C != pk.c or not x.dense:
         raise MspiError("mlp: input has %d channels (dense=%s), packed for %d" % (x.C, x.dense, pk.c))
+    if pk.w.device != x.buf.device:
+        raise MspiError("mlp: packed weights live on %s, the input on %s" % (pk.w.device, x.buf.device))
     if out is None:
         out = alloc(x.N, x.T, x.H, x.W, pk.c, x.buf.device)
     if res is not None and (res.M != x.M or not res.dense):

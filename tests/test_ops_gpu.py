@@ -437,3 +437,21 @@ def test_rowgemm_thin(dev, cin, cout, M, res, gate, act):
     _close(out.as_ncdhw(), out2.as_ncdhw().cpu(), 2e-5, "thin vs tiled")
     if out.Cs > cout:   # pad channels stay exact zeros
         assert (out.as_rows()[:, cout:] == 0).all()
+
+
+@pytest.mark.parametrize("W", [32, 36])
+def test_narrow_stem_widened_conv(dev, W):
+    """ResNetBasicStem with 8 output channels (SlowFast fast pathway): the (5,7,13)/(1,2,8) x 32-channel form used when
+    W % 8 == 0 and the plain (5,7,7)/(1,2,2) form otherwise, both against torch (conv + eval BN + ReLU + max-pool)."""
+    from mspi_amd.backbones.blocks3d import ResNetBasicStem
+    from mspi_amd import testing as T
+    stem = T.seeded(lambda: ResNetBasicStem(3, 8, [5, 7, 7], [1, 2, 2], [2, 3, 3]), 1)
+    T.randomize_(stem, 2)
+    stem.eval()
+    x = torch.randn(2, 3, 6, 24, W, generator=torch.Generator().manual_seed(W))
+    with torch.no_grad():
+        ref = stem.pool_layer(F.relu(stem.bn(stem.conv(x))))
+    stem = stem.to(dev)
+    out = stem.run(x.to(dev))
+    assert stem.pk["wide"] is not None      # packed either way; run() uses it only when W % 8 == 0
+    _close(out.as_ncdhw(), ref, 2e-5, "narrow stem W=%d" % W)
