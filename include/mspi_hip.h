@@ -86,8 +86,9 @@ typedef struct MspiConvDesc {
   float w_scale;                   /* F16X3: power-of-two pre-scale of the weights (undone in the epilogue) */
   int32_t tile;                    /* -1: library heuristic; else a kernel instantiation picked by the caller's
                                       autotuner: 0 128x128/4 waves, 1 128x64, 2 128x32, 3 64x64, 4 128x128/8 waves,
-                                      5 256x128, 6..11 LDS-DMA kernel with 128 / 64 / all (<= 256) / 96 / 192 / 32 columns
-                                      per tile (f16x3, 16-B gather only) */
+                                      5 256x128, 6..11 LDS-DMA kernel (128 rows, 4 waves) with 128 / 64 / all (<= 256) /
+                                      96 / 192 / 32 columns per tile, 12..14 its 256-row / 8-wave form with 256 / 192 /
+                                      128 columns (f16x3, 16-B gather only) */
 } MspiConvDesc;
 
 int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float* w, const float* bias /*[Cout] or NULL*/,

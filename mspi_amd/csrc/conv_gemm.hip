@@ -359,7 +359,10 @@ static void launch_cfg(const ConvArgs& a, bool v4, int prec, hipStream_t s) {
 
 using namespace mspi;
 
-namespace mspi { int launch_conv_ad(ConvArgs& a, long Ml, int force_bn, int* cfg, hipStream_t s); }
+namespace mspi {
+int launch_conv_ad(ConvArgs& a, long Ml, int force_bn, int* cfg, hipStream_t s);
+int launch_conv_ad8(ConvArgs& a, long Ml, int bn, int* cfg, hipStream_t s);
+}
 
 static thread_local int g_last_cfg = 0;
 extern "C" int mspi_conv_last_config(void) { return g_last_cfg; }
@@ -412,8 +415,16 @@ extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float*
   static const int dma_mode = getenv("MSPI_CONV_DMA") ? atoi(getenv("MSPI_CONV_DMA")) : 1;   // 0 never, 1 auto, 2 always
   const bool deep_conv = (long)d->kT * d->kH * d->kW > 1 && K >= 2048 && Ml >= 16384;
   const bool dma_ok = d->prec == PREC_F16X3 && v4;
-  MSPI_REQUIRE(d->tile >= -1 && d->tile <= 11 && (d->tile < 6 || dma_ok) && (d->tile != 8 || d->Cout <= 256),
+  MSPI_REQUIRE(d->tile >= -1 && d->tile <= 14 && (d->tile < 6 || dma_ok) && (d->tile != 8 || d->Cout <= 256),
                "mspi_conv_fwd: tile %d not available for this call", d->tile);
+  if (d->tile >= 12) {   // LDS-DMA kernel with a 256-row tile and 8 waves sharing one weight tile
+    static const int bn8[3] = {256, 192, 128};
+    int cfg = 0;
+    const int rc = launch_conv_ad8(a, Ml, bn8[d->tile - 12], &cfg, (hipStream_t)stream);
+    MSPI_REQUIRE(rc == 0, "mspi_conv_fwd: tile %d could not be launched", d->tile);
+    g_last_cfg = cfg;
+    return check_launch("mspi_conv_fwd");
+  }
   if (dma_ok && (d->tile >= 6 || (d->tile < 0 && (dma_mode == 2 || (dma_mode == 1 && deep_conv))))) {
     static const int dma_bn[6] = {128, 64, 1, 96, 192, 32};   // tile 6..11 (1 = all columns in one tile)
     int cfg = 0;

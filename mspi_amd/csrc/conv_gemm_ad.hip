@@ -23,14 +23,17 @@ __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f}
 typedef __attribute__((address_space(3))) void lds_void;
 
 // DENSE: 1x1x1, stride 1, no padding -- a plain GEMM on rows; the per-stage source address is base + k, no tap cursor
-template <int BN, bool GATE, bool DENSE>
-__global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p) {
-  constexpr int BM = 128;
+// NW: waves per workgroup = 32-row slabs of the tile (4: 128 x BN, two workgroups per CU; 8: 256 x BN, one workgroup per
+// CU whose eight waves share ONE weight tile -- 1.67x fewer staged bytes per MFMA and a 1.33x longer compute phase to
+// cover the latency of the next stage's DMA)
+template <int BN, bool GATE, bool DENSE, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArgs p) {
+  constexpr int BM = 32 * NW;
   constexpr int TN = BN / 32;
   constexpr int A_BYTES = BM * 32 * 4;          // raw fp32 activations: 128 rows x 32 k
   constexpr int P_BYTES = BN * 32 * 2;          // one f16 weight plane: BN rows x 32 k
   constexpr int STAGE = A_BYTES + 2 * P_BYTES;
-  constexpr int HBI = (BN + 63) / 64;           // weight DMA instructions per wave per plane (16 rows each)
+  constexpr int HBI = (BN + 16 * NW - 1) / (16 * NW);   // weight DMA instructions per wave per plane (16 rows each)
   static_assert(BN % 32 == 0 && BN >= 32 && BN <= 256, "BN: multiple of 32, <= 256");
   // Ring depth: 3 stages (two K steps of DMA in flight behind a COUNTED vmcnt + raw s_barrier, so the barrier does
   // not drain the newest stage) where 3 stages still leave two workgroups per CU, else 2 stages.
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p)
   const int li = lane & 31, lh = lane >> 5;
   const int logical = xcd_logical_block(blockIdx.x, p.nblocks);
   const int tile_n = logical % p.tiles_n, tile_m = logical / p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;   // BM = 32 NW
   const int ntaps = p.kT * p.kH * p.kW;
 
   // ---- activation DMA assignment: instruction j fills LDS chunks (j*4+wave)*64 + lane (16 B each):
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p)
   bool a_ok[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    int m = m0 + (j * 4 + wave) * 8 + (lane >> 3);
+    int m = m0 + (j * NW + wave) * 8 + (lane >> 3);
     a_ok[j] = m < p.M;
     if (!a_ok[j]) m = 0;
     const int wo = m % p.Wo;
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float* src = (kin && a_ok[j]) ? p.x + a_off[j] + kk : g_zero16;
-        __builtin_amdgcn_global_load_lds(src, (lds_void*)(base + (j * 4 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src, (lds_void*)(base + (j * NW + wave) * 1024), 16, 0, 0);
       }
     } else {
       const bool kin = ktap < ntaps;
@@ -97,20 +100,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p)
         const bool inb = kin && a_ok[j] && (unsigned)(a_t[j] + kdt) < (unsigned)p.T &&
                          (unsigned)(a_h[j] + kdh) < (unsigned)p.H && (unsigned)(a_w[j] + kdw) < (unsigned)p.W;
         const float* src = inb ? p.x + a_off[j] + koff : g_zero16;
-        __builtin_amdgcn_global_load_lds(src, (lds_void*)(base + (j * 4 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src, (lds_void*)(base + (j * NW + wave) * 1024), 16, 0, 0);
       }
     }
 #pragma unroll
     for (int i = 0; i < HBI; ++i) {
-      if ((i * 4 + wave) * 16 < BN) {   // wave-uniform: the last group of 16 rows may not exist for this wave
-        const int r = (i * 4 + wave) * 16 + (lane >> 2);
+      if ((i * NW + wave) * 16 < BN) {   // wave-uniform: the last group of 16 rows may not exist for this wave
+        const int r = (i * NW + wave) * 16 + (lane >> 2);
         const int n = n0 + r;
         const bool ok = n < p.Cout;
         const _Float16* q = wh + (long)(ok ? n : 0) * p.ldw + k0 + b_seg * 8;
         const void* s_hi = ok ? (const void*)q : (const void*)g_zero16;
         const void* s_lo = ok ? (const void*)(q + wplane) : (const void*)g_zero16;
-        __builtin_amdgcn_global_load_lds(s_hi, (lds_void*)(base + A_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(s_lo, (lds_void*)(base + A_BYTES + P_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(s_hi, (lds_void*)(base + A_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(s_lo, (lds_void*)(base + A_BYTES + P_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
       }
     }
     if (!DENSE) {
@@ -286,14 +289,30 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvArgs p)
 
 // returns 0 when launched, -100 when this path does not apply (caller falls back to conv_gemm.hip).
 // force_bn: 0 = heuristic; else the column tile (a multiple of 32 up to 256; 1 = "all columns in one tile").
-template <int BN>
+template <int BN, int NW = 4>
 static void launch_bn(const ConvArgs& a, hipStream_t s) {
-  const dim3 g(a.nblocks), b(256);
+  const dim3 g(a.nblocks), b(64 * NW);
   const bool dense = a.kT * a.kH * a.kW == 1 && a.strT == 1 && a.strH == 1 && a.strW == 1 && a.padT == 0 && a.padH == 0 &&
                      a.padW == 0;
-  if (a.gate) hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, true, true>), g, b, 0, s, a);   // the gate implies 1x1x1
-  else if (dense) hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, false, true>), g, b, 0, s, a);
-  else hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, false, false>), g, b, 0, s, a);
+  if (a.gate) hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, true, true, NW>), g, b, 0, s, a);   // the gate implies 1x1x1
+  else if (dense) hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, false, true, NW>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, false, false, NW>), g, b, 0, s, a);
+}
+
+// 256 x BN tile, 8 waves (tile codes 12..14)
+int launch_conv_ad8(ConvArgs& a, long Ml, int bn, int* cfg, hipStream_t s) {
+  a.tiles_n = (int)((a.Cout + bn - 1) / bn);
+  const long nb = ((Ml + 255) / 256) * a.tiles_n;
+  if (nb >= (1L << 31)) return -100;
+  a.nblocks = (int)nb;
+  *cfg = (256 << 16) | (bn << 4) | 8 | (PREC_F16X3 << 1) | 4;
+  switch (bn) {
+    case 128: launch_bn<128, 8>(a, s); break;
+    case 192: launch_bn<192, 8>(a, s); break;
+    case 256: launch_bn<256, 8>(a, s); break;
+    default: return -100;
+  }
+  return 0;
 }
 
 int launch_conv_ad(ConvArgs& a, long Ml, int force_bn_arg, int* cfg, hipStream_t s) {

@@ -464,6 +464,8 @@ def conv(x, pk, out=None, res=None, gate=None, act=None, tile=None):
             cands = [1, 2, 3, 4]
             if pk.prec == PREC_F16X3 and d.sC == 1 and Cin % 4 == 0:
                 cands += [6, 7, 9, 10] + ([8] if pk.cout_s <= 256 else [])
+                if M >= 16384:
+                    cands += [12, 13, 14]        # 256-row / 8-wave form of the LDS-DMA kernel
             if rg is not None:
                 cands.append(THIN)
             choice = _tune_conv(launch, key, cands)

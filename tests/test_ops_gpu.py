@@ -68,7 +68,7 @@ def test_conv(dev, case, act, prec):
         assert torch.isfinite(out.buf).all()
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
 @pytest.mark.parametrize("shape", [
     (2, 96, 2, 9, 11, 200, (1, 1, 1), (1, 1, 1), (0, 0, 0)),     # plain GEMM, ragged M, N not a tile multiple
     (1, 56, 3, 10, 9, 96, (3, 3, 3), (1, 2, 2), (1, 1, 1)),      # strided multi-tap conv, padded channel count
