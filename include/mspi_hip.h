@@ -95,6 +95,15 @@ int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float* w, const f
                   const float* res /*NULL or [M][ldr]*/, const float* gate /*NULL or [N][C]*/,
                   float* y, mspi_stream_t stream);
 
+/* Split-K form of mspi_conv_fwd for problems with few output tiles and a long contraction (M*Cout small, K large:
+ * the SA / smoothing convs on 14x14 maps, the audio ResNet's last stages, SlowFast s5): ksplit workgroups share each
+ * 64x64 output tile, each owns a contiguous range of K steps and writes its partial sums to the workspace
+ * (mspi_conv_splitk_ws_bytes(d, ksplit) bytes); a second launch adds the slices in order and applies bias, residual and
+ * activation -- bitwise reproducible, no atomics.  No gate; Cout % 4 == 0. */
+size_t mspi_conv_splitk_ws_bytes(const MspiConvDesc* d, int32_t ksplit);
+int mspi_conv_splitk_fwd(const MspiConvDesc* d, const float* x, const float* w, const float* bias, const float* res,
+                         float* y, void* workspace, int32_t ksplit, mspi_stream_t stream);
+
 /* Which kernel instantiation the calling thread's last mspi_conv_fwd launched:
  * (BM << 16) | (BN << 4) | (8 if 8 waves) | (4 if LDS-DMA staging) | (prec << 1) | (1 if scalar gather, 0 if
  * 16-B vector gather).  For profiling: it names the template instantiation rocprofv3 reports. */

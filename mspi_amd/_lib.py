@@ -91,6 +91,8 @@ _SIGNATURES = {
     "mspi_last_error": (C.c_char_p, []),
     "mspi_device_count": (C.c_int, []),
     "mspi_conv_last_config": (C.c_int, []),
+    "mspi_conv_splitk_ws_bytes": (C.c_size_t, [C.POINTER(ConvDesc), C.c_int32]),
+    "mspi_conv_splitk_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "mspi_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "mspi_dwconv_fwd": (C.c_int, [C.POINTER(DwConvDesc), _P, _P, _P, _P, _P, _P]),
     "mspi_dwconv_pool_rows": (C.c_int, [C.POINTER(DwConvDesc)]),

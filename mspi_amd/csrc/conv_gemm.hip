@@ -86,7 +86,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
   const int hseg = tid & 3, hrow = tid >> 2;
 
   // ---- k cursor of this thread's float4 (V4 loader): (tap, c) and tap -> (dt,dh,dw) ----
-  int kc = kv * 4, ktap = 0, kdt = 0, kdh = 0, kdw = 0;
+  const int nk = (int)((p.ldw + BK - 1) / BK);          // ldw >= K by contract; [K, ldw) is zero in w and masked in A
+  const int it_begin = p.ws ? (int)((long)nk * blockIdx.y / p.ksplit) : 0;
+  const int it_end = p.ws ? (int)((long)nk * (blockIdx.y + 1) / p.ksplit) : nk;
+  int kc = kv * 4 + it_begin * BK, ktap = 0, kdt = 0, kdh = 0, kdw = 0;
   if (LOADER == LOAD_V4) {
     ktap = kc / p.C;
     kc -= ktap * p.C;
@@ -195,7 +198,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int Kloop = (int)p.ldw;  // ldw >= K by contract; [K, ldw) is zero in w and masked in A
   const int li = lane & 31, lh = lane >> 5;
 
   // registers -> LDS stage `st` (F16X3: split every fp32 activation into hi + lo halves on the way)
@@ -299,18 +301,37 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
   // Software pipeline: while stage `cur` is being multiplied, tile it+1 (already in registers) is split and
   // written to the other stage and tile it+2 is requested from memory -- one barrier per K step, two tiles of
   // global-load latency cover.
-  const int nk = (Kloop + BK - 1) / BK;
-  load_tiles(0);
-  store_tiles(0);
-  if (nk > 1) load_tiles(BK);
-  __syncthreads();
-  for (int it = 0; it < nk; ++it) {
-    const int cur = it & 1;
+  if (it_begin < it_end) {
+    load_tiles(it_begin * BK);
+    store_tiles(0);
+    if (it_begin + 1 < it_end) load_tiles((it_begin + 1) * BK);
+    __syncthreads();
+  }
+  for (int it = it_begin; it < it_end; ++it) {
+    const int cur = (it - it_begin) & 1;
     if (!(p.dbg & 8)) compute_half(cur, 0);
-    if (it + 1 < nk && !(p.dbg & 4)) store_tiles(cur ^ 1);
-    if (it + 2 < nk && !(p.dbg & 2)) load_tiles((it + 2) * BK);
+    if (it + 1 < it_end && !(p.dbg & 4)) store_tiles(cur ^ 1);
+    if (it + 2 < it_end && !(p.dbg & 2)) load_tiles((it + 2) * BK);
     if (!(p.dbg & 8)) compute_half(cur, 1);
     __syncthreads();
+  }
+  if (p.ws) {   // split-K: raw partial sums, reduced in a fixed order by splitk_reduce_kernel
+    float* wz = p.ws + (long)blockIdx.y * p.M * p.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+      if (col >= p.Cout) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int rb0 = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rb0 + (r & 3) + 8 * (r >> 2);
+          if (row < p.M) wz[(long)row * p.Cout + col] = PREC == PREC_F32 ? acc[i][j][r] : acc[i][j][r] * p.out_scale;
+        }
+      }
+    }
+    return;
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
@@ -345,7 +366,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
 
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(const ConvArgs& a, bool v4, int prec, hipStream_t s) {
-  const dim3 g(a.nblocks), b(WM * WN * 64);
+  const dim3 g(a.nblocks, a.ws ? a.ksplit : 1), b(WM * WN * 64);
   if (prec == PREC_F32) {
     if (v4) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, LOAD_V4, PREC_F32>), g, b, 0, s, a);
     else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, LOAD_S, PREC_F32>), g, b, 0, s, a);
@@ -367,8 +388,30 @@ int launch_conv_ad8(ConvArgs& a, long Ml, int bn, int* cfg, hipStream_t s);
 static thread_local int g_last_cfg = 0;
 extern "C" int mspi_conv_last_config(void) { return g_last_cfg; }
 
-extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float* w, const float* bias,
-                             const float* res, const float* gate, float* y, mspi_stream_t stream) {
+namespace mspi {
+// y = act( sum_z ws[z] + bias + res ): the K slices' partial sums, added in slice order (bitwise reproducible)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, long M, int Cout,
+                                                            const float* __restrict__ bias, const float* __restrict__ res,
+                                                            long ldr, float* __restrict__ y, long ldy, int act) {
+  const long total = M * (Cout >> 2);
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % (Cout >> 2)) * 4;
+    const long row = idx / (Cout >> 2);
+    float4 a = *reinterpret_cast<const float4*>(ws + row * Cout + c);
+    for (int z = 1; z < S; ++z) {
+      const float4 b = *reinterpret_cast<const float4*>(ws + ((long)z * M + row) * Cout + c);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + c); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    if (res) { const float4 b = *reinterpret_cast<const float4*>(res + row * ldr + c); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    a.x = act_apply(a.x, act); a.y = act_apply(a.y, act); a.z = act_apply(a.z, act); a.w = act_apply(a.w, act);
+    *reinterpret_cast<float4*>(y + row * ldy + c) = a;
+  }
+}
+}  // namespace mspi
+
+static int conv_fwd_impl(const MspiConvDesc* d, const float* x, const float* w, const float* bias, const float* res,
+                         const float* gate, float* y, float* ws, int ksplit, mspi_stream_t stream) {
   MSPI_REQUIRE(d && x && w && y, "mspi_conv_fwd: null argument");
   MSPI_REQUIRE(d->N > 0 && d->T > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->Cout > 0, "mspi_conv_fwd: empty extent");
   MSPI_REQUIRE(d->kT > 0 && d->kH > 0 && d->kW > 0 && d->strT > 0 && d->strH > 0 && d->strW > 0 && d->padT >= 0 &&
@@ -408,6 +451,26 @@ extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float*
   a.out_scale = d->prec == PREC_F16X3 ? 1.0f / d->w_scale : 1.0f;
   static const int dbg = getenv("MSPI_CONV_DBG") ? atoi(getenv("MSPI_CONV_DBG")) : 0;
   a.dbg = dbg;
+  a.ws = ws; a.ksplit = ksplit;
+  if (ws) {
+    // split-K (mspi_conv_splitk_fwd): 64x64 tiles, gridDim.y = ksplit slices of the K loop, then the ordered reduction
+    MSPI_REQUIRE(!gate && (d->Cout & 3) == 0 && (d->ldy & 3) == 0 && (!res || (d->ldr & 3) == 0) && aligned16(y) && aligned16(ws) &&
+                     (!res || aligned16(res)) && (!bias || aligned16(bias)),
+                 "mspi_conv_splitk_fwd: no gate; Cout / ldy / ldr multiples of 4; 16-B aligned pointers");
+    MSPI_REQUIRE(ksplit >= 2 && ksplit <= 64 && ksplit <= (d->ldw + BK - 1) / BK, "mspi_conv_splitk_fwd: ksplit = %d", ksplit);
+    a.tiles_n = (d->Cout + 63) / 64;
+    const long nb = ((Ml + 63) / 64) * a.tiles_n;
+    MSPI_REQUIRE(nb < (1L << 31), "mspi_conv_splitk_fwd: grid too large");
+    a.nblocks = (int)nb;
+    hipStream_t s = (hipStream_t)stream;
+    g_last_cfg = (64 << 16) | (64 << 4) | (d->prec << 1) | (v4 ? 0 : 1);
+    launch_cfg<64, 64, 2, 2>(a, v4, d->prec, s);
+    const long total = Ml * (d->Cout >> 2);
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(mspi::splitk_reduce_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, ws, ksplit,
+                       Ml, d->Cout, bias, res, (long)d->ldr, y, (long)d->ldy, d->act);
+    return check_launch("mspi_conv_splitk_fwd");
+  }
 
   // LDS-DMA form (conv_gemm_ad.hip): measured faster than the register-staged kernel on deep implicit GEMMs
   // (multi-tap convs, K >= 2048: 208 vs 199 TFLOP/s on the 3x3x3 readout conv), slower on the 1x1x1 layers
@@ -472,4 +535,20 @@ extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float*
     default: launch_cfg<64, 64, 2, 2>(a, v4, d->prec, s); break;
   }
   return check_launch("mspi_conv_fwd");
+}
+
+extern "C" int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float* w, const float* bias,
+                             const float* res, const float* gate, float* y, mspi_stream_t stream) {
+  return conv_fwd_impl(d, x, w, bias, res, gate, y, nullptr, 1, stream);
+}
+
+extern "C" size_t mspi_conv_splitk_ws_bytes(const MspiConvDesc* d, int32_t ksplit) {
+  if (!d || ksplit < 2) return 0;
+  return (size_t)ksplit * (size_t)d->N * d->To * d->Ho * d->Wo * d->Cout * sizeof(float);
+}
+
+extern "C" int mspi_conv_splitk_fwd(const MspiConvDesc* d, const float* x, const float* w, const float* bias,
+                                    const float* res, float* y, void* workspace, int32_t ksplit, mspi_stream_t stream) {
+  MSPI_REQUIRE(workspace, "mspi_conv_splitk_fwd: null workspace");
+  return conv_fwd_impl(d, x, w, bias, res, nullptr, y, (float*)workspace, ksplit, stream);
 }

@@ -60,7 +60,9 @@ def load_autotune(path):
     return len(AUTOTUNE["cache"])
 
 
-THIN = 100            # kernel choice "row-stationary thin GEMM" next to MspiConvDesc.tile codes 0..11
+THIN = 100            # kernel choice "row-stationary thin GEMM" next to MspiConvDesc.tile codes 0..14
+SPLITK = 200          # kernel choice SPLITK + S: split-K with S slices (mspi_conv_splitk_fwd)
+SPLITK_ENABLED = _os.environ.get("MSPI_SPLITK", "1") != "0"   # A/B switch
 THIN_DEFAULT = True   # without autotuning: take the thin kernel wherever it applies
 THIN_ENABLED = _os.environ.get("MSPI_THIN", "1") != "0"   # A/B switch
 
@@ -451,6 +453,11 @@ def conv(x, pk, out=None, res=None, gate=None, act=None, tile=None):
     def launch(t):
         if t == THIN:
             return lib.mspi_rowgemm_fwd(C.byref(rg), *rg_args)
+        if t >= SPLITK:      # split-K: t - SPLITK slices of the contraction, partial sums through a scratch buffer
+            S = t - SPLITK
+            ws = torch.empty(S * M * pk.cout_s, dtype=torch.float32, device=dev)   # stream-ordered: safe to drop after the launch
+            d.tile = 3
+            return lib.mspi_conv_splitk_fwd(C.byref(d), args[0], args[1], args[2], args[3], args[5], ws.data_ptr(), S, args[6])
         d.tile = t
         return lib.mspi_conv_fwd(C.byref(d), *args)
 
@@ -468,6 +475,10 @@ def conv(x, pk, out=None, res=None, gate=None, act=None, tile=None):
                     cands += [12, 13, 14]        # 256-row / 8-wave form of the LDS-DMA kernel
             if rg is not None:
                 cands.append(THIN)
+            nk = pk.ldw // 32
+            if SPLITK_ENABLED and gate is None and -(-M // 64) * -(-pk.cout_s // 64) <= 384 and nk >= 32:
+                # few output tiles, long contraction: K slices across workgroups (mspi_conv_splitk_fwd)
+                cands += [SPLITK + S for S in (2, 4, 8) if nk >= 8 * S]
             choice = _tune_conv(launch, key, cands)
     elif key in AUTOTUNE["cache"]:
         choice = AUTOTUNE["cache"][key]
@@ -476,10 +487,12 @@ def conv(x, pk, out=None, res=None, gate=None, act=None, tile=None):
     if choice == THIN and rg is None:
         raise MspiError("conv: the thin-GEMM kernel does not cover this call")
     with tm:
-        check(launch(choice), "mspi_rowgemm_fwd" if choice == THIN else "mspi_conv_fwd")
+        check(launch(choice), "mspi_rowgemm_fwd" if choice == THIN else "mspi_conv_splitk_fwd" if choice >= SPLITK else "mspi_conv_fwd")
         if Profiler.active is not None:
             if choice == THIN:
                 tm.name = "rowgemm<%d,f16x3>" % rowgemm_ksb(pk.cin_s)
+            elif choice >= SPLITK:
+                tm.name = "conv_gemm<64,64,splitk%d>" % (choice - SPLITK)
             else:
                 c = lib.mspi_conv_last_config()
                 tm.name = "conv_gemm<%d,%d,%s,%s>" % (c >> 16, (c >> 4) & 0xFFF,

@@ -455,3 +455,30 @@ def test_narrow_stem_widened_conv(dev, W):
     out = stem.run(x.to(dev))
     assert stem.pk["wide"] is not None      # packed either way; run() uses it only when W % 8 == 0
     _close(out.as_ncdhw(), ref, 2e-5, "narrow stem W=%d" % W)
+
+
+@pytest.mark.parametrize("S", [2, 4, 8])
+@pytest.mark.parametrize("shape", [
+    (2, 512, 4, 7, 7, 96, (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # SA / smoothing convs on small maps: long K, few tiles
+    (1, 2048, 1, 5, 9, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0)),    # late 1x1x1 layers
+    (3, 40, 2, 6, 5, 24, (1, 3, 3), (1, 2, 2), (0, 1, 1)),       # K steps barely cover the slices; ragged M and N
+])
+def test_conv_split_k(dev, S, shape):
+    """mspi_conv_splitk_fwd (kernel choice SPLITK + S): K slices -> scratch partials -> ordered reduction with bias,
+    residual and ReLU; same result as the single-pass kernel to fp32 rounding, and bitwise repeatable."""
+    from mspi_amd import engine as E
+    N, Cin, T, H, W, Cout, k, s, p = shape
+    g = torch.Generator().manual_seed(Cin + S)
+    x = torch.randn(N, Cin, T, H, W, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) / math.sqrt(Cin * k[0] * k[1] * k[2])
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv3d(x.double(), w.double(), b.double(), s, p)
+    res = torch.randn(ref.shape, generator=g)
+    ref = F.relu(ref + res.double()).float()
+    pk = E.pack_conv(w, b, None, s, p, E.ACT_RELU, cin_stored=E.rup4(Cin), device=dev, prec=E.PREC_F16X3)
+    if pk.ldw // 32 < S:
+        pytest.skip("fewer K steps than slices")
+    out = E.conv(_cl(x, dev), pk, res=_cl(res, dev), tile=E.SPLITK + S)
+    _close(out.as_ncdhw(Cout), ref, 2e-5, "split-K %d %s" % (S, shape))
+    out2 = E.conv(_cl(x, dev), pk, res=_cl(res, dev), tile=E.SPLITK + S)
+    assert torch.equal(out.buf, out2.buf)
