@@ -114,7 +114,7 @@ def main():
     from mspi_amd.model.model_utils import AudioVisualSaliencyModel
 
     name, B, S = args.model, args.batch, args.size
-    t_tok = {"x3dl": 16, "slowfast4x16": 4}.get(name, 8)
+    t_tok = {"x3dl": 16, "slowfast4x16": 4, "s3d": 4}.get(name, 8)
     cfg = T.make_cfg(name, num_aud_tokens=9 * ((args.wa + 31) // 32), num_vis_tokens=t_tok * (S // 32) ** 2)
     devnull = open(os.devnull, "w")
     so, sys.stdout = sys.stdout, devnull          # the constructors print; keep stdout to the one JSON line

@@ -256,7 +256,7 @@ def build_model(model_name, resolution, wa=111, weight=None, use_sound=True):
     """cfg for `model_name` with the SyncBlock tables sized for `resolution` / a 257 x wa spectrogram."""
     from . import testing as T
     from .model.model_utils import AudioVisualSaliencyModel, VisualSaliencyModel
-    t_tok = {"x3dl": 16, "slowfast4x16": 4}.get(model_name, 8)
+    t_tok = {"x3dl": 16, "slowfast4x16": 4, "s3d": 4}.get(model_name, 8)
     cfg = T.make_cfg(model_name, num_aud_tokens=9 * ((wa + 31) // 32),
                      num_vis_tokens=t_tok * (resolution[0] // 32) * (resolution[1] // 32))
     cfg.DATA.RESOLUTION = tuple(resolution)

@@ -22,7 +22,10 @@ def video_motion_extractor(cfg):
         from ..backbones.video_swin_transformer import SwinTransformer3D
         depths = cfg.MODEL.get("SWIN", {}).get("DEPTHS", [2, 2, 18, 2])
         motion_encoder = SwinTransformer3D(depths=list(depths))
-    elif name in ("s3d", "morphmlps", "uniformerb"):
+    elif name == "s3d":
+        from ..backbones.s3d import S3D_features_only
+        motion_encoder = S3D_features_only(pool=cfg.MODEL.S3D.POOL_STRIDE)
+    elif name in ("morphmlps", "uniformerb"):
         raise NotImplementedError("motion encoder %r is outside the MI355X hot-path scope (SURVEY.md section 8f)" % name)
     if motion_encoder is None:
         raise Exception("Invalid Motion Encoder!")

@@ -61,14 +61,18 @@ def build_reference_model(name, cls_name, num_vis_tokens=None):
     rh.set_create_model(lambda *a, **k: _RefConvNeXt())
     import model.model_utils as mu
     import backbones.sf as ref_sf
+    import backbones.s3d as ref_s3d
     real_load, real_lsd, real_sf_lw = torch.load, nn.Module.load_state_dict, ref_sf.SlowFast.load_weight
+    real_s3d_lw = ref_s3d.S3D_features_only.load_weight
     ref_sf.SlowFast.load_weight = lambda self, path: None    # caffe2 .pkl loader opens the (absent) file itself
+    ref_s3d.S3D_features_only.load_weight = lambda self, path: None   # raises on the absent file before any torch.load
     torch.load = lambda *a, **k: _NoWeights()
     nn.Module.load_state_dict = lambda self, sd, *a, **k: None if isinstance(sd, _NoWeights) else real_lsd(self, sd, *a, **k)
     try:
         m = getattr(mu, cls_name)(cfg)
     finally:
         torch.load, nn.Module.load_state_dict, ref_sf.SlowFast.load_weight = real_load, real_lsd, real_sf_lw
+        ref_s3d.S3D_features_only.load_weight = real_s3d_lw
     return m.eval()
 
 
@@ -128,6 +132,24 @@ def case_x3dl_backbone(size=64, seed=0):
         ora = R.x3d_forward(sd, clips)
     _check_restatement("x3dl backbone", feats, ora)
     _save("x3dl_backbone_%d" % size, seed=seed, size=size, batch=2, sd_crc=T.sd_checksum(sd), **_feat_fixture(feats))
+
+
+def case_s3d_backbone(size=64, seed=0):
+    """S3D_features_only (backbones/s3d.py:379-421) with the product's seeded + randomised state dict, strict load."""
+    from mspi_amd.backbones.s3d import S3D_features_only
+    prod = T.seeded(lambda: S3D_features_only(), seed)
+    T.randomize_(prod, seed + 1)
+    sd = prod.state_dict()
+    rh.with_config("x3dl")                         # enters the reference tree (stubs, sys.path); the config itself is unused
+    from backbones.s3d import S3D_features_only as RefS3D
+    ref = RefS3D(pool=1).eval()
+    ref.load_state_dict(sd, strict=True)
+    clips, _ = T.synth_inputs(2, 16, size, size, seed=seed)
+    with torch.no_grad():
+        feats = ref(clips)
+        ora = R.s3d_forward(sd, clips)
+    _check_restatement("s3d backbone", feats, ora)
+    _save("s3d_backbone_%d" % size, seed=seed, size=size, batch=2, sd_crc=T.sd_checksum(sd), **_feat_fixture(feats))
 
 
 def case_slowfast_backbone(size=64, seed=0):
@@ -217,7 +239,7 @@ def case_resnet18_audio(seed=0):
 
 def _model_case(name, cls_name, size, B, wa, seed, tag):
     from mspi_amd.model import model_utils as pm
-    t_tok = {"x3dl": 16, "slowfast4x16": 4}.get(name, 8)
+    t_tok = {"x3dl": 16, "slowfast4x16": 4, "s3d": 4}.get(name, 8)
     nvt = t_tok * (size // 32) ** 2
     aud_tok = 9 * ((wa + 31) // 32)
     pcfg = T.make_cfg(name, num_aud_tokens=aud_tok, num_vis_tokens=nvt)
@@ -253,6 +275,11 @@ def case_av_x3dl_64():
 
 def case_av_x3dl_224():
     _model_case("x3dl", "AudioVisualSaliencyModel", 224, 1, 300, 0, "av_x3dl_224")
+
+
+def case_av_s3d_64():
+    """t tokens = 4 (16 frames / 2 in the stem / 2 in maxpooling3), so 4 * (64/32)^2 visual tokens."""
+    _model_case("s3d", "AudioVisualSaliencyModel", 64, 2, 111, 0, "av_s3d_64")
 
 
 def case_vis_x3dl_64():

@@ -497,14 +497,52 @@ def pack_clips(name, clips):
     """model/model_utils.py:521-532: SlowFast slow pathway = frames [0,4,12,-1] (F7)."""
     if name == "slowfast4x16":
         return [torch.stack([clips[:, :, 0], clips[:, :, 4], clips[:, :, 12], clips[:, :, -1]], 2), clips]
-    if name == "videoswins":
+    if name in ("videoswins", "s3d"):
         return clips
     return [clips]
+
+
+# ------------------------------------------------------------------------------- S3D (SURVEY 8f rank 4)
+def _s3d_sep(sd, p, x, k, s, pad):
+    """SepConv3d, backbones/s3d.py:95-116: (1,k,k)/(1,s,s) conv + BN + ReLU, then (k,1,1)/(s,1,1) conv + BN + ReLU."""
+    x = F.relu(_bn(sd, p + ".bn_s", _conv3(sd, p + ".conv_s", x, (1, s, s), (0, pad, pad)), 1e-3))
+    return F.relu(_bn(sd, p + ".bn_t", _conv3(sd, p + ".conv_t", x, (s, 1, 1), (pad, 0, 0)), 1e-3))
+
+
+def _s3d_mixed(sd, p, x):
+    """Mixed_3b .. Mixed_5c, backbones/s3d.py:118-370: four branches concatenated on channels."""
+    x0 = basic_conv3d(sd, p + ".branch0.0", x, 0)
+    x1 = _s3d_sep(sd, p + ".branch1.1", basic_conv3d(sd, p + ".branch1.0", x, 0), 3, 1, 1)
+    x2 = _s3d_sep(sd, p + ".branch2.1", basic_conv3d(sd, p + ".branch2.0", x, 0), 3, 1, 1)
+    x3 = basic_conv3d(sd, p + ".branch3.1", F.max_pool3d(x, 3, 1, 1), 0)
+    return torch.cat((x0, x1, x2, x3), 1)
+
+
+def s3d_forward(sd, clips, prefix="", pool=1):
+    """S3D_features_only.forward, backbones/s3d.py:379-421 -> [base1, base2, base3, base4]."""
+    p = prefix
+    x = _s3d_sep(sd, p + "base1.0", clips, 7, 2, 3)
+    x = F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    x = basic_conv3d(sd, p + "base1.2", x, 0)
+    base1 = _s3d_sep(sd, p + "base1.3", x, 3, 1, 1)
+    x = F.max_pool3d(base1, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    for i in range(2):
+        x = _s3d_mixed(sd, p + "base2.%d" % i, x)
+    base2 = x
+    x = F.max_pool3d(base2, 3, 2, 1)
+    for i in range(5):
+        x = _s3d_mixed(sd, p + "base3.%d" % i, x)
+    base3 = x
+    x = F.max_pool3d(base3, (pool, 2, 2), (pool, 2, 2))
+    for i in range(2):
+        x = _s3d_mixed(sd, p + "base4.%d" % i, x)
+    return [base1, base2, base3, x]
 
 
 BACKBONES = {}  # name -> fn(sd, packed_clips, prefix) -> [v1..v4]; filled below and by restate_tx.py
 BACKBONES["x3dl"] = lambda sd, x, prefix: x3d_forward(sd, x[0], prefix)
 BACKBONES["slowfast4x16"] = lambda sd, x, prefix: slowfast_forward(sd, x, prefix)
+BACKBONES["s3d"] = lambda sd, x, prefix: s3d_forward(sd, x, prefix)
 MVIT_S_ARCH = {   # configs/MVITv2_S_16x4.yaml resolved the way MViT.__init__ does (backbones/MViT.py:1779-1826)
     "patch_stride": (2, 4, 4), "patch_padding": (1, 3, 3),
     "blocks": [(1, (1, 1, 1), (1, 8, 8)), (2, (1, 2, 2), (1, 4, 4)), (2, (1, 1, 1), (1, 4, 4)), (4, (1, 2, 2), (1, 2, 2))]

@@ -41,6 +41,22 @@ def test_x3dl_backbone(golden_dir):
         assert T.feature_error(f, g, "v%d" % (i + 1)) <= 1e-6
 
 
+def test_s3d_backbone(golden_dir):
+    """S3D_features_only; the fixture is the reference's own forward on the product's state dict."""
+    from mspi_amd.backbones.s3d import S3D_features_only
+    g = _g(golden_dir, "s3d_backbone_64")
+    m = T.seeded(lambda: S3D_features_only(), int(g["seed"]))
+    T.randomize_(m, int(g["seed"]) + 1)
+    sd = m.state_dict()
+    assert len(sd) == 462 and T.sd_checksum(sd) == int(g["sd_crc"])
+    clips, _ = T.synth_inputs(int(g["batch"]), 16, int(g["size"]), int(g["size"]), seed=int(g["seed"]))
+    with torch.no_grad():
+        feats = R.s3d_forward(sd, clips)
+    assert [f.shape[1] for f in feats] == [192, 480, 832, 1024]
+    for i, f in enumerate(feats):
+        assert T.feature_error(f, g, "v%d" % (i + 1)) <= 1e-6
+
+
 def test_slowfast_backbone(golden_dir):
     from mspi_amd.backbones.sf import SlowFast
     from mspi_amd.config import cfg
@@ -124,7 +140,7 @@ def _model(g, name, cls):
 
 
 @pytest.mark.parametrize("case,name", [("av_x3dl_64", "x3dl"), ("av_x3dl_224", "x3dl"), ("av_slowfast_64", "slowfast4x16"),
-                                       ("av_mvit_224", "mvitv2s"), ("av_swin_s_224", "videoswins")])
+                                       ("av_mvit_224", "mvitv2s"), ("av_swin_s_224", "videoswins"), ("av_s3d_64", "s3d")])
 def test_audio_visual_model(golden_dir, case, name):
     g = _g(golden_dir, case)
     cfg, sd, clips, audio = _model(g, name, "AudioVisualSaliencyModel")

@@ -37,6 +37,18 @@ def test_x3dl_backbone_vs_golden(dev, golden_dir):
     assert T.feature_error(f2[3].flip(0), g, "v4") < 1e-4
 
 
+def test_s3d_backbone_vs_golden(dev, golden_dir):
+    from mspi_amd.backbones.s3d import S3D_features_only
+    g = _g(golden_dir, "s3d_backbone_64")
+    m = T.seeded(lambda: S3D_features_only(), int(g["seed"]))
+    T.randomize_(m, int(g["seed"]) + 1)
+    m = m.to(dev)
+    clips, _ = T.synth_inputs(int(g["batch"]), 16, int(g["size"]), int(g["size"]), seed=int(g["seed"]), device=dev)
+    feats = m(clips)
+    for i, f in enumerate(feats):
+        assert T.feature_error(f, g, "v%d" % (i + 1)) < 1e-4, "v%d" % (i + 1)
+
+
 def test_slowfast_backbone_vs_golden(dev, golden_dir):
     from mspi_amd.backbones.sf import SlowFast
     from mspi_amd.config import cfg
@@ -90,7 +102,7 @@ def _build(g, name, cls, dev):
 
 
 @pytest.mark.parametrize("case,name", [("av_x3dl_64", "x3dl"), ("av_x3dl_224", "x3dl"), ("av_slowfast_64", "slowfast4x16"),
-                                       ("av_mvit_224", "mvitv2s"), ("av_swin_s_224", "videoswins")])
+                                       ("av_mvit_224", "mvitv2s"), ("av_swin_s_224", "videoswins"), ("av_s3d_64", "s3d")])
 def test_audio_visual_model_vs_golden(dev, golden_dir, case, name):
     g = _g(golden_dir, case)
     cfg, m, clips, audio = _build(g, name, "AudioVisualSaliencyModel", dev)

@@ -10,7 +10,7 @@ from mspi_amd.model.model_utils import AudioVisualSaliencyModel
 dev = torch.device("cuda")
 name = sys.argv[1] if len(sys.argv) > 1 else "x3dl"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-t_tok = {"x3dl": 16, "slowfast4x16": 4}.get(name, 8)
+t_tok = {"x3dl": 16, "slowfast4x16": 4, "s3d": 4}.get(name, 8)
 cfg = T.make_cfg(name, num_aud_tokens=90, num_vis_tokens=t_tok * 49)
 so, sys.stdout = sys.stdout, open(os.devnull, "w")
 m = T.seeded(lambda: AudioVisualSaliencyModel(cfg), 0).to(dev)
