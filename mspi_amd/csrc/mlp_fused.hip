@@ -300,12 +300,12 @@ struct RowGemmArgs {
   int rows_per_sample;
 };
 
-constexpr int RG_LDS = 72 * 1024;   // static: LDS budget of one workgroup (rowgemm_cps keeps cps * (SB + 128) below it)
+constexpr int RG_LDS = 64 * 1024;   // dynamic LDS budget of one workgroup (rowgemm_cps keeps cps * (SB + 128) below it: no opt-in needed)
 
 template <int KSB, bool GATE>
 __global__ __launch_bounds__(256, 2) void rowgemm_kernel(const RowGemmArgs p) {
   constexpr int SB = KSB * 2048;                 // bytes of one 32-column chunk: [ks][hi,lo][lane][8 halves]
-  __shared__ __attribute__((aligned(16))) unsigned char rg_smem[RG_LDS];   // cps * SB weights, then cps*32 bias floats
+  extern __shared__ __attribute__((aligned(16))) unsigned char rg_smem[];   // cps * SB weights, then cps*32 bias floats
   const int j0 = blockIdx.y * p.cps;
   const int nj = min(p.cps, p.nch - j0);
   float* bs = reinterpret_cast<float*>(rg_smem + (size_t)p.cps * SB);
@@ -404,8 +404,8 @@ __global__ __launch_bounds__(256, 2) void rowgemm_kernel(const RowGemmArgs p) {
 template <int KSB>
 static int launch_rowgemm(const RowGemmArgs& a, size_t lds, hipStream_t s) {
   const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.nch + a.cps - 1) / a.cps));
-  if (a.gate) hipLaunchKernelGGL((rowgemm_kernel<KSB, true>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((rowgemm_kernel<KSB, false>), grid, dim3(256), 0, s, a);
+  if (a.gate) hipLaunchKernelGGL((rowgemm_kernel<KSB, true>), grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((rowgemm_kernel<KSB, false>), grid, dim3(256), lds, s, a);
   return 0;
 }
 
