@@ -197,6 +197,14 @@ typedef struct MspiMvitAugDesc {
 int mspi_mvit_qk_augment(const MspiMvitAugDesc* d, const float* q, const float* k, const float* Rh, const float* Rw,
                          const float* Rt, float* qa, float* ka, mspi_stream_t stream);
 
+/* Same result with the dot products done by a GEMM: P[(b*Nq + tok)*heads + head][ldp] = q_row . T^T, T = the rows of the
+ * three (length-matched) relative-position tables stacked; idx_h [qH][kH], idx_w [qW][kW], idx_t [qT][kT] give the column
+ * of P that holds q . R*[position, j] (the relative distance of backbones/MViT.py:905-990 plus the table's offset).  The
+ * caller computes P with mspi_conv_fwd / mspi_rowgemm_fwd on the q rows; this call only copies and gathers. */
+int mspi_mvit_qk_augment_p(const MspiMvitAugDesc* d, const float* q, const float* k, const float* P, int64_t ldp,
+                           const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t, float* qa, float* ka,
+                           mspi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Max pooling, channels-last, -inf padding.
  * Replaces nn.MaxPool3d / MaxPool2d at model/model_utils.py:189,206;

@@ -102,6 +102,7 @@ _SIGNATURES = {
     "mspi_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mspi_space_to_depth": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mspi_mvit_qk_augment": (C.c_int, [C.POINTER(MvitAugDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mspi_mvit_qk_augment_p": (C.c_int, [C.POINTER(MvitAugDesc), _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "mspi_maxpool_fwd": (C.c_int, [C.POINTER(DwConvDesc), _P, _P, _P]),
     "mspi_upsample_fwd": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, _P]),

@@ -12,6 +12,8 @@ Per block on channels-last token rows (the '(t h w) c' order IS the CL layout, s
 Reversible-MViT / cls-token / absolute-position variants are dead for MSPI's config and not built."""
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -42,6 +44,9 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv3d(dim_in, dim_out, kernel_size=kernel, stride=stride, padding=padding)
 
 
+REL_GEMM = os.environ.get("MSPI_MVIT_REL_GEMM", "1") != "0"   # A/B switch: relative-position dot products as a GEMM
+
+
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features, out_features):
         super().__init__()
@@ -50,9 +55,10 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features)
 
 
-def _rel_tables(rel_pos, q_size, k_size):
-    """Gathered table R[q][k][c] = rel_pos'[dist(q,k)] (cal_rel_pos_spatial/temporal, backbones/MViT.py:905-990),
-    with get_rel_pos's linear interpolation (:207-220) when the stored table has a different length."""
+def _rel_rows(rel_pos, q_size, k_size):
+    """(length-matched table [2 max(q,k) - 1, head_dim], index dist[q][k] into it): rel_pos'[dist(q,k)] of
+    cal_rel_pos_spatial/temporal (backbones/MViT.py:905-990), with get_rel_pos's linear interpolation (:207-220) when the
+    stored table has a different length."""
     d = int(2 * max(q_size, k_size) - 1)
     tab = rel_pos.detach().float()
     if tab.shape[0] != d:
@@ -62,7 +68,13 @@ def _rel_tables(rel_pos, q_size, k_size):
     k_ratio = max(q_size / k_size, 1.0)
     dist = torch.arange(q_size)[:, None] * q_ratio - torch.arange(k_size)[None, :] * k_ratio
     dist += (k_size - 1) * k_ratio
-    return tab[dist.long().to(tab.device)].contiguous()      # [q_size, k_size, head_dim]
+    return tab, dist.long()
+
+
+def _rel_tables(rel_pos, q_size, k_size):
+    """Gathered table R[q][k][c] = rel_pos'[dist(q,k)]."""
+    tab, dist = _rel_rows(rel_pos, q_size, k_size)
+    return tab[dist.to(tab.device)].contiguous()      # [q_size, k_size, head_dim]
 
 
 class MultiScaleAttention(nn.Module):
@@ -131,8 +143,16 @@ class MultiScaleBlock(HipModule):
         key = (tuple(q_thw), tuple(k_thw))
         if key not in pk["rel"]:
             a = self.attn
-            pk["rel"][key] = (_rel_tables(a.rel_pos_h, q_thw[1], k_thw[1]), _rel_tables(a.rel_pos_w, q_thw[2], k_thw[2]),
-                              _rel_tables(a.rel_pos_t, q_thw[0], k_thw[0]))
+            gathered = (_rel_tables(a.rel_pos_h, q_thw[1], k_thw[1]), _rel_tables(a.rel_pos_w, q_thw[2], k_thw[2]),
+                        _rel_tables(a.rel_pos_t, q_thw[0], k_thw[0]))
+            # GEMM form: all distinct table rows stacked [Dh + Dw + Dt, head_dim] as a Linear layer, plus, per axis, the
+            # column of that stack which holds the row for (own position, key position)
+            (th, dh), (tw, dw), (tt, dt) = (_rel_rows(a.rel_pos_h, q_thw[1], k_thw[1]), _rel_rows(a.rel_pos_w, q_thw[2], k_thw[2]),
+                                            _rel_rows(a.rel_pos_t, q_thw[0], k_thw[0]))
+            dev = th.device
+            stack = torch.cat([th, tw, tt], 0)
+            idx = [d_.to(torch.int32).contiguous().to(dev) + off for d_, off in ((dh, 0), (dw, th.shape[0]), (dt, th.shape[0] + tw.shape[0]))]
+            pk["rel"][key] = gathered + ((E.pack_conv(stack, None), idx[0], idx[1], idx[2]),)
         return pk["rel"][key]
 
     def run(self, x):
@@ -154,8 +174,9 @@ class MultiScaleBlock(HipModule):
             return t
 
         q, k, v = head_ln(q, pk["nq"]), head_ln(k, pk["nk"]), head_ln(v, pk["nv"])
-        Rh, Rw, Rt = self._rel(pk, q_thw, k_thw)
-        o = E.mvit_attention(q, k, v, B, heads, hd, a.scale, q_thw, k_thw, Rh, Rw, Rt)
+        Rh, Rw, Rt, rel_gemm = self._rel(pk, q_thw, k_thw)
+        o = E.mvit_attention(q, k, v, B, heads, hd, a.scale, q_thw, k_thw, Rh, Rw, Rt,
+                             rel_gemm=rel_gemm if REL_GEMM and E.DEFAULT_PREC == E.PREC_F16X3 else None)
         skip = E.conv(xn, pk["skip"]) if "skip" in pk else x          # DIM_MUL_IN_ATT: proj(norm1(x)) (MViT.py:1414-1415)
         if self.pool_skip is not None:
             skip = E.maxpool(skip, self.kernel_skip, self.stride_skip, tuple(int(kk // 2) for kk in self.kernel_skip))

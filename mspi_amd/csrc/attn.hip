@@ -483,9 +483,70 @@ __global__ __launch_bounds__(256) void mvit_aug_rel_kernel(const AugArgs p) {
   }
 }
 
+// (2') the same J columns gathered from P = Q . [all distinct relative-position rows]^T, a dense thin GEMM the caller ran
+// before (mspi_mvit_qk_augment_p): q . R*[own position, j] = P[row][index of the distance (own position, j)] -- the
+// 96-long dot products move onto the matrix pipe and this kernel only moves 4 bytes per (row, j).
+struct GatherArgs {
+  const float* P;        // [(b*Nq + tok)*heads + head][ldp]
+  const int* idx_h;      // [qH][kH] column of P
+  const int* idx_w;      // [qW][kW]
+  const int* idx_t;      // [qT][kT]
+  float* qa;
+  long ldp;
+  int B, heads, Dh, DA, qT, qH, qW, kT, kH, kW;
+};
+
+__global__ __launch_bounds__(256) void mvit_aug_gather_kernel(const GatherArgs p) {
+  const int Nq = p.qT * p.qH * p.qW;
+  const int J = p.kH + p.kW + p.kT, J4 = (p.Dh + J + 3) / 4 * 4 - p.Dh;
+  const long qrows = (long)p.B * p.heads * Nq;
+  const long row = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int j = threadIdx.x & 31;
+  if (row >= qrows) return;
+  const int tok = (int)(row % Nq);
+  const long bh = row / Nq;
+  const float* pr = p.P + (((bh / p.heads) * Nq + tok) * p.heads + bh % p.heads) * p.ldp;
+  const int wq = tok % p.qW, hq = (tok / p.qW) % p.qH, tq = tok / (p.qW * p.qH);
+  for (int jj = j; jj < J4; jj += 32) {
+    float v = 0.f;
+    if (jj < J) {
+      const int col = jj < p.kH ? p.idx_h[hq * p.kH + jj]
+                    : jj < p.kH + p.kW ? p.idx_w[wq * p.kW + (jj - p.kH)] : p.idx_t[tq * p.kT + (jj - p.kH - p.kW)];
+      v = pr[col];
+    }
+    p.qa[row * p.DA + p.Dh + jj] = v;
+  }
+}
+
 }  // namespace mspi
 
 using namespace mspi;
+
+extern "C" int mspi_mvit_qk_augment_p(const MspiMvitAugDesc* d, const float* q, const float* k, const float* P, int64_t ldp,
+                                      const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t, float* qa, float* ka,
+                                      mspi_stream_t stream) {
+  MSPI_REQUIRE(d && q && k && P && idx_h && idx_w && idx_t && qa && ka, "mspi_mvit_qk_augment_p: null argument");
+  MSPI_REQUIRE(d->B > 0 && d->heads > 0 && d->Dh > 0 && (d->Dh & 3) == 0 && (d->DA & 3) == 0 &&
+                   d->DA >= d->Dh + d->kH + d->kW + d->kT, "mspi_mvit_qk_augment_p: DA=%d too small", d->DA);
+  MSPI_REQUIRE((d->ldq & 3) == 0 && (d->ldk & 3) == 0 && aligned16(q) && aligned16(k), "mspi_mvit_qk_augment_p: 16-B alignment");
+  AugArgs a;
+  a.q = q; a.k = k; a.Rh = nullptr; a.Rw = nullptr; a.Rt = nullptr; a.qa = qa; a.ka = ka;
+  a.B = d->B; a.heads = d->heads; a.Dh = d->Dh; a.DA = d->DA;
+  a.qT = d->qT; a.qH = d->qH; a.qW = d->qW; a.kT = d->kT; a.kH = d->kH; a.kW = d->kW;
+  a.ldq = d->ldq; a.ldk = d->ldk; a.scale = d->scale;
+  const long qrows = (long)d->B * d->heads * d->qT * d->qH * d->qW;
+  const long total = (qrows + (long)d->B * d->heads * d->kT * d->kH * d->kW) * (d->DA / 4);
+  long g = (total + 255) / 256;
+  if (g > 256L * 32) g = 256L * 32;
+  MSPI_REQUIRE((qrows + 7) / 8 < (1L << 31), "mspi_mvit_qk_augment_p: too many rows");
+  hipLaunchKernelGGL(mvit_aug_copy_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
+  GatherArgs ga;
+  ga.P = P; ga.idx_h = idx_h; ga.idx_w = idx_w; ga.idx_t = idx_t; ga.qa = qa; ga.ldp = ldp;
+  ga.B = d->B; ga.heads = d->heads; ga.Dh = d->Dh; ga.DA = d->DA;
+  ga.qT = d->qT; ga.qH = d->qH; ga.qW = d->qW; ga.kT = d->kT; ga.kH = d->kH; ga.kW = d->kW;
+  hipLaunchKernelGGL(mvit_aug_gather_kernel, dim3((unsigned)((qrows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, ga);
+  return check_launch("mspi_mvit_qk_augment_p");
+}
 
 extern "C" int mspi_mvit_qk_augment(const MspiMvitAugDesc* d, const float* q, const float* k, const float* Rh,
                                     const float* Rw, const float* Rt, float* qa, float* ka, mspi_stream_t stream) {

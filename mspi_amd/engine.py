@@ -662,9 +662,12 @@ def space_to_depth(x, out=None):
     return out
 
 
-def mvit_attention(q, k, v, B, heads, hd, scale, q_thw, k_thw, Rh, Rw, Rt, out=None):
+def mvit_attention(q, k, v, B, heads, hd, scale, q_thw, k_thw, Rh, Rw, Rt, out=None, rel_gemm=None):
     """MViTv2 pooled attention with decomposed relative positions and residual pooling (backbones/MViT.py:1261-1301).
     q: CL rows (b, tq,hq,wq) x heads*hd (pooled + normed); k, v likewise over the pooled key grid.
+    Rh / Rw / Rt: gathered tables [q_size][k_size][hd].  rel_gemm = (packed_tables, idx_h, idx_w, idx_t): the q . R dot
+    products as ONE thin GEMM of the q rows against all distinct table rows (pack_conv of their stack) followed by a gather
+    (mspi_mvit_qk_augment_p) instead of the per-(row, j) dot-product kernel.
     Returns CL rows (b, q token) x heads*hd = softmax(...) v + q."""
     lib = _lib.load()
     Nq, Nk = q_thw[0] * q_thw[1] * q_thw[2], k_thw[0] * k_thw[1] * k_thw[2]
@@ -680,9 +683,17 @@ def mvit_attention(q, k, v, B, heads, hd, scale, q_thw, k_thw, Rh, Rw, Rt, out=N
     a.qT, a.qH, a.qW = q_thw
     a.kT, a.kH, a.kW = k_thw
     a.ldq, a.ldk, a.scale = q.ld, k.ld, float(scale)
-    with _Timed("mvit_qk_augment", 2.0 * B * heads * Nq * J * hd, 4.0 * B * heads * (Nq + Nk) * (hd + DA)):
-        check(lib.mspi_mvit_qk_augment(C.byref(a), q.ptr, k.ptr, Rh.data_ptr(), Rw.data_ptr(), Rt.data_ptr(),
-                                       qa.data_ptr(), ka.data_ptr(), _stream()), "mspi_mvit_qk_augment")
+    if rel_gemm is not None and q.dense and q.ld == heads * hd:
+        pkT, idx_h, idx_w, idx_t = rel_gemm
+        rows = CL(q.buf, q.off, q.M * heads, 1, 1, 1, hd, hd)           # (b, token, head) rows of hd channels
+        P = conv(rows, pkT)
+        with _Timed("mvit_qk_augment", 0.0, 4.0 * B * heads * (Nq + Nk) * (hd + DA)):
+            check(lib.mspi_mvit_qk_augment_p(C.byref(a), q.ptr, k.ptr, P.ptr, P.ld, idx_h.data_ptr(), idx_w.data_ptr(),
+                                             idx_t.data_ptr(), qa.data_ptr(), ka.data_ptr(), _stream()), "mspi_mvit_qk_augment_p")
+    else:
+        with _Timed("mvit_qk_augment", 2.0 * B * heads * Nq * J * hd, 4.0 * B * heads * (Nq + Nk) * (hd + DA)):
+            check(lib.mspi_mvit_qk_augment(C.byref(a), q.ptr, k.ptr, Rh.data_ptr(), Rw.data_ptr(), Rt.data_ptr(),
+                                           qa.data_ptr(), ka.data_ptr(), _stream()), "mspi_mvit_qk_augment")
     if out is None:
         out = alloc(q.N, q.T, q.H, q.W, heads * hd, dev)
     d = AttnDesc()

@@ -281,7 +281,14 @@ def test_mvit_attention(dev, q_thw, k_thw, heads):
     q = torch.randn(B, Nq, heads * hd, generator=g)
     k = torch.randn(B, Nk, heads * hd, generator=g)
     v = torch.randn(B, Nk, heads * hd, generator=g)
-    Rt, Rh, Rw = (torch.randn(q_thw[i], k_thw[i], hd, generator=g) * 0.3 for i in range(3))
+    # tables of distinct relative distances and the (own position, key position) -> row index, as MViT builds them
+    tabs, dists = [], []
+    for i in range(3):
+        n = 2 * max(q_thw[i], k_thw[i]) - 1
+        tabs.append(torch.randn(n, hd, generator=g) * 0.3)
+        qr, kr = max(k_thw[i] / q_thw[i], 1.0), max(q_thw[i] / k_thw[i], 1.0)
+        dists.append((torch.arange(q_thw[i])[:, None] * qr - torch.arange(k_thw[i])[None, :] * kr + (k_thw[i] - 1) * kr).long())
+    Rt, Rh, Rw = (tabs[i][dists[i]] for i in range(3))
     qh = q.view(B, Nq, heads, hd).transpose(1, 2).double()
     kh = k.view(B, Nk, heads, hd).transpose(1, 2).double()
     vh = v.view(B, Nk, heads, hd).transpose(1, 2).double()
@@ -299,6 +306,15 @@ def test_mvit_attention(dev, q_thw, k_thw, heads):
     out = E.mvit_attention(cl(q, q_thw), cl(k, k_thw), cl(v, k_thw), B, heads, hd, hd ** -0.5, q_thw, k_thw,
                            Rh.to(dev).contiguous(), Rw.to(dev).contiguous(), Rt.to(dev).contiguous())
     _close(out.as_rows().view(B, Nq, heads * hd), ref, 2e-5, "mvit attention")
+    if E.DEFAULT_PREC == E.PREC_F16X3:
+        # the q . R dot products as one thin GEMM against the stacked distinct rows + a gather (mspi_mvit_qk_augment_p)
+        stack = torch.cat([tabs[1], tabs[2], tabs[0]], 0)           # h, w, t
+        offs = (0, tabs[1].shape[0], tabs[1].shape[0] + tabs[2].shape[0])
+        idx = [(dists[a].to(torch.int32) + o).contiguous().to(dev) for a, o in zip((1, 2, 0), offs)]
+        rel = (E.pack_conv(stack, None, device=dev), idx[0], idx[1], idx[2])
+        out2 = E.mvit_attention(cl(q, q_thw), cl(k, k_thw), cl(v, k_thw), B, heads, hd, hd ** -0.5, q_thw, k_thw,
+                                Rh.to(dev).contiguous(), Rw.to(dev).contiguous(), Rt.to(dev).contiguous(), rel_gemm=rel)
+        _close(out2.as_rows().view(B, Nq, heads * hd), ref, 2e-5, "mvit attention, GEMM rel-pos")
 
 
 def test_attention_large_logits(dev):
