@@ -202,3 +202,21 @@ def test_full_size_determinism_under_allocator_churn(dev):
             junk.pop(0)
         out = m(clips, audio)[0]
         assert torch.equal(out, ref), "forward %d differs from the first one (max %.3e)" % (i, (out - ref).abs().max().item())
+
+
+@pytest.mark.parametrize("name,B,H,W,wa", [("x3dl", 3, 96, 160, 300), ("s3d", 2, 128, 96, 111)])
+def test_rectangular_frames_and_odd_batch_vs_oracle(dev, name, B, H, W, wa):
+    """Non-square frames (inference.py's default is 224x384), an odd batch, both spectrogram widths: HIP vs the oracle
+    run on the host (no fixture: the oracle is pinned by the golden tests above)."""
+    from mspi_amd.model.model_utils import AudioVisualSaliencyModel
+    from oracle import restate as R
+    t_tok = {"x3dl": 16, "s3d": 4}[name]
+    cfg = T.make_cfg(name, num_aud_tokens=9 * ((wa + 31) // 32), num_vis_tokens=t_tok * (H // 32) * (W // 32))
+    m = T.seeded(lambda: AudioVisualSaliencyModel(cfg), 0)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    clips, audio = T.synth_inputs(B, 16, H, W, Wa=wa, seed=2)
+    out, loss = m.to(dev)(clips.to(dev), audio.to(dev))
+    with torch.no_grad():
+        ref, rl = R.audio_visual_forward(sd, clips, audio, name, cfg.MODEL.LATERAL_BOOL, cfg.MODEL.LATERAL_STRIDE)
+    assert tuple(out.shape) == (B, H, W)
+    assert (out.cpu() - ref).abs().max().item() < MAP_TOL and abs(loss.item() - rl.item()) < MAP_TOL
