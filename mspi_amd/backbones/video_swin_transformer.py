@@ -54,15 +54,19 @@ def compute_mask(D, H, W, window_size, shift_size):
     return torch.where(diff != 0, torch.tensor(-100.0), torch.tensor(0.0))
 
 
-def window_token_index(D, H, W, window_size, shift_size):
+def window_token_index(D, H, W, window_size, shift_size, padded=None):
     """int32 [nW, N]: row (within a sample's D*H*W token rows) of token t of window w after the cyclic shift
-    roll(x, -shift) and window_partition (reference :61-70,255-262)."""
+    roll(x, -shift) and window_partition (reference :61-70,255-262).  padded = (Dp, Hp, Wp): the grid is zero-padded to
+    multiples of the window first (reference :240-246); padding positions map to the extra row D*H*W."""
     wd, wh, ww = window_size
-    d = (torch.arange(D) + shift_size[0]) % D
-    h = (torch.arange(H) + shift_size[1]) % H
-    w = (torch.arange(W) + shift_size[2]) % W
+    Dp, Hp, Wp = padded if padded is not None else (D, H, W)
+    d = (torch.arange(Dp) + shift_size[0]) % Dp
+    h = (torch.arange(Hp) + shift_size[1]) % Hp
+    w = (torch.arange(Wp) + shift_size[2]) % Wp
     rows = (d[:, None, None] * H + h[None, :, None]) * W + w[None, None, :]          # shifted position -> source row
-    rows = rows.view(D // wd, wd, H // wh, wh, W // ww, ww).permute(0, 2, 4, 1, 3, 5).reshape(-1, wd * wh * ww)
+    inside = (d[:, None, None] < D) & (h[None, :, None] < H) & (w[None, None, :] < W)
+    rows = torch.where(inside, rows, torch.full_like(rows, D * H * W))
+    rows = rows.view(Dp // wd, wd, Hp // wh, wh, Wp // ww, ww).permute(0, 2, 4, 1, 3, 5).reshape(-1, wd * wh * ww)
     return rows.to(torch.int32).contiguous()
 
 
@@ -114,9 +118,7 @@ class SwinTransformerBlock3D(HipModule):
         key = (D, H, W)
         if key not in pk["geo"]:
             ws, ss = get_window_size((D, H, W), self.window_size, self.shift_size)
-            if D % ws[0] or H % ws[1] or W % ws[2]:
-                raise MspiError("Video-Swin: token grid %s is not a multiple of the window %s (the reference zero-pads; "
-                                "not built -- use 224x224 clips)" % ((D, H, W), ws))
+            Dp, Hp, Wp = (-(-D // ws[0]) * ws[0], -(-H // ws[1]) * ws[1], -(-W // ws[2]) * ws[2])   # reference :240-246
             a = self.attn
             dev = a.qkv.weight.device
             N = reduce(mul, ws)
@@ -125,18 +127,32 @@ class SwinTransformerBlock3D(HipModule):
             biasT = bias.permute(2, 1, 0).contiguous().to(dev)                                  # [head, k, q]
             maskT = None
             if any(s > 0 for s in ss):
-                maskT = compute_mask(D, H, W, ws, ss).transpose(1, 2).contiguous().to(dev)      # [nW, k, q]
-            pk["geo"][key] = (N, window_token_index(D, H, W, ws, ss).to(dev), biasT, maskT)
+                maskT = compute_mask(Dp, Hp, Wp, ws, ss).transpose(1, 2).contiguous().to(dev)   # [nW, k, q]
+            padded = (Dp, Hp, Wp) != (D, H, W)
+            pk["geo"][key] = (N, window_token_index(D, H, W, ws, ss, (Dp, Hp, Wp)).to(dev), biasT, maskT, padded)
         return pk["geo"][key]
 
     def run(self, x):
         pk, a = self.pk, self.attn
-        N, tok_idx, biasT, maskT = self._geometry(pk, x.T, x.H, x.W)
-        xn = E.layernorm(x, *pk["n1"], 1e-5)
-        qkv = E.conv(xn, pk["qkv"])
+        N, tok_idx, biasT, maskT, padded = self._geometry(pk, x.T, x.H, x.W)
         nwin = tok_idx.shape[0]
-        o = E.attention(qkv, x.N * nwin, N, a.num_heads, self.dim // a.num_heads, a.scale, biasT=biasT, maskT=maskT,
-                        tok_idx=tok_idx)
+        if not padded:
+            xn = E.layernorm(x, *pk["n1"], 1e-5)
+            qkv = E.conv(xn, pk["qkv"])
+            o = E.attention(qkv, x.N * nwin, N, a.num_heads, self.dim // a.num_heads, a.scale, biasT=biasT, maskT=maskT,
+                            tok_idx=tok_idx)
+        else:
+            # The reference zero-pads norm1(x) up to a multiple of the window (:240-246), so a padding token enters the
+            # attention as qkv(0) = the qkv bias.  All padding tokens share ONE extra row per sample: row D*H*W of the
+            # normed buffer is zero, the qkv GEMM turns it into the bias, tok_idx points every padding position at it,
+            # and what the attention writes back for those positions lands in that row of `o` and is never read.
+            R = x.T * x.H * x.W
+            xn = E.alloc(x.N, R + 1, 1, 1, x.C, x.buf.device)
+            xn.buf.view(x.N, R + 1, xn.ld)[:, R].zero_()
+            E.layernorm(x, *pk["n1"], 1e-5, out=xn.tokens(0, x.T, x.H, x.W))
+            qkv = E.conv(xn, pk["qkv"])
+            o = E.attention(qkv, x.N * nwin, N, a.num_heads, self.dim // a.num_heads, a.scale, biasT=biasT, maskT=maskT,
+                            tok_idx=tok_idx, rows_per_sample=R + 1).tokens(0, x.T, x.H, x.W)
         x = E.conv(o, pk["proj"], res=x)
         return E.mlp_tail(x, pk["mlp"], pk["n2"], 1e-5, res=x)   # dim 96 / 192: one fused launch (mspi_mlp_fwd)
 

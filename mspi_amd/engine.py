@@ -581,22 +581,25 @@ def layernorm(x, gamma, beta, eps, out=None, act=ACT_NONE, table=None):
     return out
 
 
-def attention(qkv, B, Ntok, heads, hd, scale, out=None, biasT=None, maskT=None, tok_idx=None):
+def attention(qkv, B, Ntok, heads, hd, scale, out=None, biasT=None, maskT=None, tok_idx=None, rows_per_sample=None):
     """qkv: CL with rows (b, token) and 3*heads*hd columns laid out [3][heads][hd]
     (what `qkv.reshape(B,N,3,h,hd)` means, model/model_utils.py:100).  B sequences of Ntok tokens.
     biasT [heads][Ntok][Ntok] / maskT [nmask][Ntok][Ntok]: key-major additive terms (Swin).
     tok_idx int32 [nwin][Ntok]: the B = samples*nwin sequences are windows whose token t sits at row
-    tok_idx[win][t] of its sample (shifted-window attention without gather/scatter passes)."""
+    tok_idx[win][t] of its sample (shifted-window attention without gather/scatter passes).
+    rows_per_sample: rows of qkv (and of the output) per sample when that is not nwin*Ntok -- Swin on a grid that is
+    not a multiple of the window keeps ONE extra row per sample for all padding tokens (tok_idx points there)."""
     lib = _lib.load()
     Cc = heads * hd
-    assert qkv.C == 3 * Cc and qkv.M == B * Ntok and qkv.dense
+    assert qkv.C == 3 * Cc and qkv.dense and (rows_per_sample is not None or qkv.M == B * Ntok)
     if out is None:
         out = alloc(qkv.N, qkv.T, qkv.H, qkv.W, Cc, qkv.buf.device)
     d = AttnDesc()
     d.B, d.Hh, d.Nq, d.Nk, d.D, d.Dv = B, heads, Ntok, Ntok, hd, hd
     d.nmask = 0 if maskT is None else maskT.shape[0]
     d.nwin = 0 if tok_idx is None else tok_idx.shape[0]
-    rows_per_sample = Ntok * max(d.nwin, 1)
+    if rows_per_sample is None:
+        rows_per_sample = Ntok * max(d.nwin, 1)
     d.q_sB = d.k_sB = d.v_sB = rows_per_sample * qkv.ld
     d.q_sH = d.k_sH = d.v_sH = hd
     d.q_sT = d.k_sT = d.v_sT = qkv.ld

@@ -207,6 +207,26 @@ def case_swin_backbone(seed=0):
     _save("swin_t_backbone_224", seed=seed, size=224, batch=1, sd_crc=T.sd_checksum(sd), **_feat_fixture(feats))
 
 
+def case_swin_backbone_padded(seed=0):
+    """Swin-T depths on 128x192 frames (the aspect of the reference's default 224x384): token grids 32x48 and 16x24 are
+    not multiples of the 7x7 window, so stages 1-2 run the reference's zero-padding path (:240-246, :419-423), with the
+    shifted-window mask on the padded grid; stages 3-4 (8x12, 4x6) clamp the window instead."""
+    from mspi_amd.backbones.video_swin_transformer import SwinTransformer3D
+    prod = T.seeded(lambda: SwinTransformer3D(depths=[2, 2, 6, 2]), seed)
+    sd = prod.state_dict()
+    rh.with_config("videoswins")
+    from backbones.video_swin_transformer import SwinTransformer3D as RefSwin
+    ref = RefSwin(depths=[2, 2, 6, 2])
+    ref.eval()
+    ref.load_state_dict(sd, strict=True)
+    clips, _ = T.synth_inputs(2, 16, 128, 192, seed=seed)
+    with torch.no_grad():
+        feats = ref(clips)
+        ora = R.swin_forward(sd, clips)
+    _check_restatement("swin-T backbone, padded windows", feats, ora, 5e-5)
+    _save("swin_t_backbone_128x192", seed=seed, H=128, W=192, batch=2, sd_crc=T.sd_checksum(sd), **_feat_fixture(feats))
+
+
 def case_av_swin_224():
     """Full AV model with the reference's default SwinTransformer3D() = Swin-S."""
     _model_case("videoswins", "AudioVisualSaliencyModel", 224, 1, 111, 0, "av_swin_s_224")

@@ -245,11 +245,13 @@ def _swin_mask(D, H, W, ws, ss):
 
 
 def swin_block(sd, p, x, heads, window, shift, mask):
-    """SwinTransformerBlock3D + WindowAttention3D (backbones/video_swin_transformer.py:108-293); no padding case."""
-    B, D, H, W, Cc = x.shape
-    ws, ss = _swin_window_size((D, H, W), window, shift)
-    assert D % ws[0] == 0 and H % ws[1] == 0 and W % ws[2] == 0
+    """SwinTransformerBlock3D + WindowAttention3D (backbones/video_swin_transformer.py:108-293), with the zero padding
+    of the normed tokens up to a multiple of the window (:240-246) and the crop after the window merge (:271-274)."""
+    B, D0, H0, W0, Cc = x.shape
+    ws, ss = _swin_window_size((D0, H0, W0), window, shift)
     h = _ln(sd, p + ".norm1", x)
+    h = F.pad(h, (0, 0, 0, (ws[2] - W0 % ws[2]) % ws[2], 0, (ws[1] - H0 % ws[1]) % ws[1], 0, (ws[0] - D0 % ws[0]) % ws[0]))
+    _, D, H, W, _ = h.shape
     shifted = any(i > 0 for i in ss)
     if shifted:
         h = torch.roll(h, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
@@ -268,7 +270,7 @@ def swin_block(sd, p, x, heads, window, shift, mask):
     o = o.view(B, D // ws[0], H // ws[1], W // ws[2], ws[0], ws[1], ws[2], Cc).permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, D, H, W, Cc)
     if shifted:
         o = torch.roll(o, shifts=ss, dims=(1, 2, 3))
-    x = x + o
+    x = x + o[:, :D0, :H0, :W0]
     return x + _lin(sd, p + ".mlp.fc2", F.gelu(_lin(sd, p + ".mlp.fc1", _ln(sd, p + ".norm2", x))))
 
 
@@ -283,7 +285,7 @@ def swin_forward(sd, clips, prefix="", window=(8, 7, 7), heads=(3, 6, 12, 24)):
     while "%slayers.%d.blocks.0.norm1.weight" % (p, li) in sd:
         B, D, H, W, Cc = x.shape
         ws, ss = _swin_window_size((D, H, W), window, shift)
-        mask = _swin_mask(D, H, W, ws, ss)
+        mask = _swin_mask(-(-D // ws[0]) * ws[0], -(-H // ws[1]) * ws[1], -(-W // ws[2]) * ws[2], ws, ss)   # :419-423
         bi = 0
         while "%slayers.%d.blocks.%d.norm1.weight" % (p, li, bi) in sd:
             x = swin_block(sd, "%slayers.%d.blocks.%d" % (p, li, bi), x, heads[li], window,

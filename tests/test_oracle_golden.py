@@ -103,6 +103,20 @@ def test_swin_backbone(golden_dir):
         assert T.feature_error(f, g, "v%d" % (i + 1)) <= 1e-6
 
 
+def test_swin_backbone_padded_windows(golden_dir):
+    """128x192 frames: token grids that are not multiples of the 7x7 window (the reference's zero-padding path)."""
+    from mspi_amd.backbones.video_swin_transformer import SwinTransformer3D
+    g = _g(golden_dir, "swin_t_backbone_128x192")
+    m = T.seeded(lambda: SwinTransformer3D(depths=[2, 2, 6, 2]), int(g["seed"]))
+    sd = m.state_dict()
+    assert T.sd_checksum(sd) == int(g["sd_crc"])
+    clips, _ = T.synth_inputs(int(g["batch"]), 16, int(g["H"]), int(g["W"]), seed=int(g["seed"]))
+    with torch.no_grad():
+        feats = R.swin_forward(sd, clips)
+    for i, f in enumerate(feats):
+        assert T.feature_error(f, g, "v%d" % (i + 1)) <= 1e-6
+
+
 def test_swin_index_and_mask_helpers():
     """The product's window index / mask helpers against roll + window_partition done with torch."""
     from mspi_amd.backbones import video_swin_transformer as S
@@ -113,6 +127,14 @@ def test_swin_index_and_mask_helpers():
     assert torch.equal(S.compute_mask(D, H, W, ws, ss), R._swin_mask(D, H, W, ws, ss))
     assert S.get_window_size((8, 56, 56), (8, 7, 7), (4, 3, 3)) == ((8, 7, 7), (0, 3, 3))
     assert S.get_window_size((8, 7, 7), (8, 7, 7), (4, 3, 3)) == ((8, 7, 7), (0, 0, 0))
+    # padded grid: positions outside D x H x W map to the extra row D*H*W, the rest to what roll + partition of the
+    # zero-padded tensor gives
+    D, H, W, ws, ss = 4, 9, 12, (4, 7, 7), (0, 3, 3)
+    Dp, Hp, Wp = 4, 14, 14
+    xp = torch.full((1, Dp, Hp, Wp, 1), float(D * H * W))
+    xp[:, :D, :H, :W, 0] = torch.arange(D * H * W, dtype=torch.float32).view(D, H, W)
+    ref = R._swin_partition(torch.roll(xp, (-ss[0], -ss[1], -ss[2]), (1, 2, 3)), ws).squeeze(-1).to(torch.int32)
+    assert torch.equal(S.window_token_index(D, H, W, ws, ss, (Dp, Hp, Wp)), ref)
 
 
 @pytest.mark.parametrize("wa", [111, 300])

@@ -82,6 +82,18 @@ def test_swin_backbone_vs_golden(dev, golden_dir):
         assert T.feature_error(f, g, "v%d" % (i + 1)) < 2e-4, "v%d" % (i + 1)
 
 
+def test_swin_backbone_padded_windows_vs_golden(dev, golden_dir):
+    """Token grids that are not multiples of the window (reference default resolution 224x384 is such a case): one extra
+    row per sample stands for every padding token; fixture = the reference's own forward on 128x192 frames."""
+    from mspi_amd.backbones.video_swin_transformer import SwinTransformer3D
+    g = _g(golden_dir, "swin_t_backbone_128x192")
+    m = T.seeded(lambda: SwinTransformer3D(depths=[2, 2, 6, 2]), int(g["seed"])).to(dev)
+    clips, _ = T.synth_inputs(int(g["batch"]), 16, int(g["H"]), int(g["W"]), seed=int(g["seed"]), device=dev)
+    feats = m(clips)
+    for i, f in enumerate(feats):
+        assert T.feature_error(f, g, "v%d" % (i + 1)) < 2e-4, "v%d" % (i + 1)
+
+
 @pytest.mark.parametrize("wa", [111, 300])
 def test_resnet18_audio_vs_golden(dev, golden_dir, wa):
     from mspi_amd.backbones.resnet import ResNet
