@@ -119,7 +119,7 @@ def main():
     devnull = open(os.devnull, "w")
     so, sys.stdout = sys.stdout, devnull          # the constructors print; keep stdout to the one JSON line
     try:
-        model = T.seeded(lambda: AudioVisualSaliencyModel(cfg), 0)
+        model = T.condition_(T.seeded(lambda: AudioVisualSaliencyModel(cfg), 0), name)
     finally:
         sys.stdout = so
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None

@@ -16,7 +16,7 @@ def _defaults():
     return AttrDict({
         "BN": {"NORM_TYPE": "batchnorm"},
         "DATA": {"INPUT_CHANNEL_NUM": [3, 3], "NUM_FRAMES": 8, "TRAIN_CROP_SIZE": 224, "TEST_CROP_SIZE": 256},
-        "MODEL": {"ARCH": "slowfast", "MODEL_NAME": "SlowFast", "DROPCONNECT_RATE": 0.0},
+        "MODEL": {"ARCH": "slowfast", "MODEL_NAME": "SlowFast", "DROPCONNECT_RATE": 0.0, "NUM_CLASSES": 400},
         "RESNET": {"TRANS_FUNC": "bottleneck_transform", "NUM_GROUPS": 1, "WIDTH_PER_GROUP": 64, "STRIDE_1X1": False,
                    "DEPTH": 50, "NUM_BLOCK_TEMP_KERNEL": [[3], [4], [6], [3]],
                    "SPATIAL_STRIDES": [[1], [2], [2], [2]], "SPATIAL_DILATIONS": [[1], [1], [1], [1]]},
@@ -34,6 +34,9 @@ def _defaults():
                  "REL_POS_ZERO_INIT": False, "RESIDUAL_POOLING": False, "DIM_MUL_IN_ATT": False,
                  "SEPARATE_QKV": False, "USE_MEAN_POOLING": False, "USE_FIXED_SINCOS_POS": False,
                  "REV": {"ENABLE": False}},
+        # backbones/Uniformer/defaults.py:404-446 (+ MODEL.NUM_CLASSES :274)
+        "UNIFORMER": {"EMBED_DIM": [64, 128, 320, 512], "DEPTH": [3, 4, 8, 3], "HEAD_DIM": 64, "MLP_RATIO": 4,
+                      "QKV_BIAS": True, "QKV_SCALE": None, "REPRESENTATION_SIZE": None, "SPLIT": False, "STD": False},
     })
 
 

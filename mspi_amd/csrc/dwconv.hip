@@ -345,12 +345,14 @@ static int fill_args(const MspiDwConvDesc* d, DwArgs& a, const char* who) {
 
 using namespace mspi;
 
-// which strip instantiation serves this descriptor: 0 = (kW 3, stride 1), 1 = (3, 2), 2 = (7, 1), -1 = generic kernel
+// which strip instantiation serves this descriptor: 0 = (kW 3, stride 1), 1 = (3, 2), 2 = (7, 1), 3 = (5, 1: UniFormer's
+// 5x5x5 local "attention"), -1 = generic kernel
 static int strip_variant(const MspiDwConvDesc* d) {
   if (d->kH != d->kW) return -1;
   if (d->kW == 3 && d->strW == 1) return 0;
   if (d->kW == 3 && d->strW == 2) return 1;
   if (d->kW == 7 && d->strW == 1) return 2;
+  if (d->kW == 5 && d->strW == 1) return 3;
   return -1;
 }
 
@@ -365,7 +367,7 @@ extern "C" int mspi_dwconv_fwd(const MspiDwConvDesc* d, const float* x, const fl
   a.x = x; a.w = w; a.bias = bias; a.y = y; a.pool = pool;
   hipStream_t s = (hipStream_t)stream;
   const int strip = strip_variant(d);
-  MSPI_REQUIRE(!pool || strip >= 0, "mspi_dwconv_fwd: SE pooling needs a (k,3,3)/(k,7,7) kernel with W-stride 1 or 2");
+  MSPI_REQUIRE(!pool || strip >= 0, "mspi_dwconv_fwd: SE pooling needs a (k,3,3)/(k,5,5)/(k,7,7) kernel with W-stride 1 or 2");
   TileCfg tc;
   if (tile_cfg(d, tc)) {
     const dim3 grid((unsigned)tc.nblk, (unsigned)tc.G, (unsigned)a.N);
@@ -391,6 +393,7 @@ extern "C" int mspi_dwconv_fwd(const MspiDwConvDesc* d, const float* x, const fl
     switch (strip) {
       case 0: MSPI_DW_LAUNCH(3, 1); break;
       case 1: MSPI_DW_LAUNCH(3, 2); break;
+      case 3: MSPI_DW_LAUNCH(5, 1); break;
       default: MSPI_DW_LAUNCH(7, 1); break;
     }
 #undef MSPI_DW_LAUNCH

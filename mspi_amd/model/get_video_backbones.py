@@ -25,7 +25,10 @@ def video_motion_extractor(cfg):
     elif name == "s3d":
         from ..backbones.s3d import S3D_features_only
         motion_encoder = S3D_features_only(pool=cfg.MODEL.S3D.POOL_STRIDE)
-    elif name in ("morphmlps", "uniformerb"):
+    elif name == "uniformerb":
+        from ..backbones.uniformer import Uniformer
+        motion_encoder = Uniformer(yaml_path=cfg.MODEL.UNIFORMER.PATH_CFG)
+    elif name == "morphmlps":
         raise NotImplementedError("motion encoder %r is outside the MI355X hot-path scope (SURVEY.md section 8f)" % name)
     if motion_encoder is None:
         raise Exception("Invalid Motion Encoder!")

@@ -104,3 +104,26 @@ def feature_error(feat, g, key):
     err = (flat[::int(g[key + "_stride"])] - ref).abs().max().item() / max(scale, 1e-6)
     merr = abs(flat.double().mean().item() - float(g[key + "_mean"])) / max(scale, 1e-6)
     return max(err, merr)
+
+
+def damp_(model, suffixes, scale=0.25, prefix=""):
+    """Scale the parameters whose names end with one of `suffixes` (and start with `prefix`) by a power of two (exact
+    on every host).  Used for deep pre-norm residual stacks (UniFormer: 40 blocks) whose variance-preserving random
+    branches would otherwise grow the activations to ~1e4, where fp32 rounding alone is 1e-3 absolute."""
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.startswith(prefix) and name.endswith(tuple(suffixes)):
+                p.mul_(scale)
+    return model
+
+
+UNIFORMER_BRANCH_OUT = (".conv2.weight", ".conv2.bias", ".mlp.fc2.weight", ".mlp.fc2.bias", ".attn.proj.weight", ".attn.proj.bias",
+                        ".pos_embed.weight", ".pos_embed.bias")
+
+
+def condition_(model, name):
+    """Per-encoder conditioning of the synthetic weights, applied after seeded(): today only UniFormer's residual
+    branches are damped (see damp_).  `model` is the bare backbone or a saliency model holding it as `.visnet`."""
+    if name == "uniformerb":
+        damp_(model, UNIFORMER_BRANCH_OUT, 0.25, "visnet." if hasattr(model, "visnet") else "")
+    return model

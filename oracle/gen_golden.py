@@ -263,7 +263,7 @@ def _model_case(name, cls_name, size, B, wa, seed, tag):
     nvt = t_tok * (size // 32) ** 2
     aud_tok = 9 * ((wa + 31) // 32)
     pcfg = T.make_cfg(name, num_aud_tokens=aud_tok, num_vis_tokens=nvt)
-    prod = T.seeded(lambda: getattr(pm, cls_name)(pcfg), seed)
+    prod = T.condition_(T.seeded(lambda: getattr(pm, cls_name)(pcfg), seed), name)
     sd = prod.state_dict()
     ref = build_reference_model(name, cls_name, num_vis_tokens=nvt)
     missing = set(ref.state_dict()) ^ set(sd)
@@ -304,6 +304,32 @@ def case_av_s3d_64():
 
 def case_vis_x3dl_64():
     _model_case("x3dl", "VisualSaliencyModel", 64, 2, 111, 0, "vis_x3dl_64")
+
+
+def case_uniformer_backbone(seed=0):
+    """Uniformer (backbones/uniformer.py:280-492, UniFormer-B per configs/uniformer_b16x4_k400.yaml) with the product's
+    seeded + randomised state dict, strict load.  64x64 batch 2 (128 / 32 tokens in the attention stages) and 224x224
+    batch 1 (1568 / 392 tokens)."""
+    from mspi_amd.backbones.uniformer import Uniformer
+    from mspi_amd.config import cfg as pcfg
+    prod = T.condition_(T.seeded(lambda: Uniformer(pcfg.MODEL.UNIFORMER.PATH_CFG), seed), "uniformerb")
+    sd = prod.state_dict()
+    rcfg = rh.with_config("uniformerb")
+    from backbones.uniformer import Uniformer as RefUni
+    ref = RefUni(yaml_path=rcfg.MODEL.UNIFORMER.PATH_CFG).eval()
+    ref.load_state_dict(sd, strict=True)
+    for size, B in ((64, 2), (224, 1)):
+        clips, _ = T.synth_inputs(B, 16, size, size, seed=seed)
+        with torch.no_grad():
+            feats = ref([clips])
+            ora = R.uniformer_forward(sd, clips)
+        scale = max(f.abs().max().item() for f in feats)
+        _check_restatement("uniformer-B backbone %d (abs-max %.1f)" % (size, scale), feats, ora, 2e-5 * max(scale, 1.0))
+        _save("uniformer_backbone_%d" % size, seed=seed, size=size, batch=B, sd_crc=T.sd_checksum(sd), **_feat_fixture(feats))
+
+
+def case_av_uniformer_64():
+    _model_case("uniformerb", "AudioVisualSaliencyModel", 64, 2, 111, 0, "av_uniformer_64")
 
 
 def c2_name_corpus():

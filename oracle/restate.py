@@ -541,10 +541,63 @@ def s3d_forward(sd, clips, prefix="", pool=1):
     return [base1, base2, base3, x]
 
 
+# ------------------------------------------------------------------------------- UniFormer-B
+def _uni_attention(sd, p, x, heads):
+    """Attention, backbones/uniformer.py:71-96 (scale = head_dim ** -0.5)."""
+    B, N, C = x.shape
+    qkv = _lin(sd, p + ".qkv", x).reshape(B, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    attn = ((qkv[0] @ qkv[1].transpose(-2, -1)) * (C // heads) ** -0.5).softmax(dim=-1)
+    return _lin(sd, p + ".proj", (attn @ qkv[2]).transpose(1, 2).reshape(B, N, C))
+
+
+def uniformer_cblock(sd, p, x):
+    """CBlock, backbones/uniformer.py:117-137: dw3x3x3 pos-embed, BN -> 1x1x1 -> dw5x5x5 -> 1x1x1, BN -> conv MLP."""
+    C = x.shape[1]
+    x = x + _conv3(sd, p + ".pos_embed", x, 1, 1, groups=C)
+    y = _conv3(sd, p + ".conv1", _bn(sd, p + ".norm1", x, 1e-5))
+    x = x + _conv3(sd, p + ".conv2", _conv3(sd, p + ".attn", y, 1, 2, groups=C))
+    y = F.gelu(_conv3(sd, p + ".mlp.fc1", _bn(sd, p + ".norm2", x, 1e-5)))
+    return x + _conv3(sd, p + ".mlp.fc2", y)
+
+
+def uniformer_sablock(sd, p, x, heads):
+    """SABlock, backbones/uniformer.py:140-163: dw3x3x3 pos-embed, pre-LN(1e-6) global attention, pre-LN MLP."""
+    B, C, T, H, W = x.shape
+    x = x + _conv3(sd, p + ".pos_embed", x, 1, 1, groups=C)
+    x = x.flatten(2).transpose(1, 2)
+    x = x + _uni_attention(sd, p + ".attn", _ln(sd, p + ".norm1", x, 1e-6), heads)
+    y = F.gelu(_lin(sd, p + ".mlp.fc1", _ln(sd, p + ".norm2", x, 1e-6)))
+    x = x + _lin(sd, p + ".mlp.fc2", y)
+    return x.transpose(1, 2).reshape(B, C, T, H, W)
+
+
+def _uni_patch_embed(sd, p, x, stride, pad):
+    """SpeicalPatchEmbed / PatchEmbed, backbones/uniformer.py:205-264: strided conv then LayerNorm(1e-5) over channels."""
+    x = _conv3(sd, p + ".proj", x, stride, pad)
+    return _ln(sd, p + ".norm", x.permute(0, 2, 3, 4, 1)).permute(0, 4, 1, 2, 3).contiguous()
+
+
+def uniformer_forward(sd, clips, prefix="", head_dim=64):
+    """Uniformer.forward_features, backbones/uniformer.py:441-474 (SPLIT False) -> the four stage outputs."""
+    p = prefix
+    feats = []
+    x = clips
+    for s, (stride, pad) in enumerate((((2, 4, 4), (1, 0, 0)), ((1, 2, 2), 0), ((1, 2, 2), 0), ((1, 2, 2), 0)), 1):
+        x = _uni_patch_embed(sd, p + "patch_embed%d" % s, x, stride, pad)
+        i = 0
+        while p + "blocks%d.%d.pos_embed.weight" % (s, i) in sd:
+            b = p + "blocks%d.%d" % (s, i)
+            x = uniformer_cblock(sd, b, x) if s <= 2 else uniformer_sablock(sd, b, x, x.shape[1] // head_dim)
+            i += 1
+        feats.append(x)
+    return feats
+
+
 BACKBONES = {}  # name -> fn(sd, packed_clips, prefix) -> [v1..v4]; filled below and by restate_tx.py
 BACKBONES["x3dl"] = lambda sd, x, prefix: x3d_forward(sd, x[0], prefix)
 BACKBONES["slowfast4x16"] = lambda sd, x, prefix: slowfast_forward(sd, x, prefix)
 BACKBONES["s3d"] = lambda sd, x, prefix: s3d_forward(sd, x, prefix)
+BACKBONES["uniformerb"] = lambda sd, x, prefix: uniformer_forward(sd, x[0], prefix)
 MVIT_S_ARCH = {   # configs/MVITv2_S_16x4.yaml resolved the way MViT.__init__ does (backbones/MViT.py:1779-1826)
     "patch_stride": (2, 4, 4), "patch_padding": (1, 3, 3),
     "blocks": [(1, (1, 1, 1), (1, 8, 8)), (2, (1, 2, 2), (1, 4, 4)), (2, (1, 1, 1), (1, 4, 4)), (4, (1, 2, 2), (1, 2, 2))]

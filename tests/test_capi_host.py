@@ -208,3 +208,36 @@ def test_autotune_cache_roundtrip(tmp_path):
     finally:
         E.AUTOTUNE["cache"].clear()
         E.AUTOTUNE["cache"].update(saved)
+
+
+def test_uniformer_folds_are_exact():
+    """UniFormer's two graph-level folds on the host: BatchNorm in front of a 1x1x1 conv folded into the conv's input
+    side, and `x + dwconv(x)` as one depthwise conv with the identity in the centre tap."""
+    from mspi_amd import engine as E
+    from mspi_amd import testing as T
+    from mspi_amd.backbones import uniformer as U
+    blk = T.seeded(lambda: U.CBlock(8, 4), 3)
+    x = torch.rand(2, 8, 3, 5, 5, generator=torch.Generator().manual_seed(1)) - 0.5
+    with torch.no_grad():
+        ref = blk.conv1(blk.norm1(x))
+        pk = U._pack_prenorm_conv(blk.norm1, blk.conv1)
+        w = (pk.w[0].double() + pk.w[1].double())[:8, :8] / pk.w_scale if pk.w.dtype == torch.float16 else pk.w[:8, :8].double()
+        got = torch.einsum("oc,ncthw->nothw", w, x.double()) + pk.bias[:8].double().view(1, -1, 1, 1, 1)
+        assert (got - ref.double()).abs().max() < 1e-5
+        ref = x + blk.pos_embed(x)
+        pd = U._pack_pos_embed(blk.pos_embed)
+        wd = pd.w[:, :8].t().reshape(8, 1, 3, 3, 3)
+        got = F.conv3d(x, wd, pd.bias[:8], 1, 1, 1, 8)
+        assert (got - ref).abs().max() < 1e-6
+
+
+def test_uniformer_factory_and_keys():
+    from mspi_amd import testing as T
+    from mspi_amd.model.get_video_backbones import video_motion_extractor
+    m = video_motion_extractor(T.make_cfg("uniformerb"))
+    keys = set(m.state_dict())
+    assert {"patch_embed1.proj.weight", "patch_embed1.norm.bias", "blocks1.4.attn.weight", "blocks2.7.mlp.fc2.bias",
+            "blocks3.19.attn.qkv.bias", "blocks4.6.mlp.fc1.weight", "norm.running_var", "head.weight"} <= keys
+    assert m.blocks1[0].attn.weight.shape == (64, 1, 5, 5, 5) and m.blocks3[0].attn.qkv.weight.shape == (960, 320)
+    with pytest.raises(NotImplementedError):
+        video_motion_extractor(T.make_cfg("morphmlps"))

@@ -146,6 +146,9 @@ DW_CASES = [
     (2, 96, 4, 8, 8, (3, 3, 3), (1, 8, 8), (1, 1, 1)),
     (1, 56, 3, 11, 13, (3, 3, 3), (1, 2, 2), (1, 1, 1)),   # odd extents: ragged strips, stride 2
     (2, 432, 2, 7, 7, (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # C/4 = 108 > strips per block
+    (2, 64, 4, 9, 10, (5, 5, 5), (1, 1, 1), (2, 2, 2)),    # UniFormer's local "attention": 5-wide strip kernel
+    (1, 128, 3, 7, 7, (5, 5, 5), (1, 1, 1), (2, 2, 2)),
+    (1, 16, 2, 6, 9, (2, 5, 4), (1, 1, 2), (0, 2, 1)),     # non-square kernel: the generic kernel
 ]
 
 
@@ -163,7 +166,7 @@ def test_dwconv_pool_maxpool(dev, case):
     _close(out.as_ncdhw(C), ref * torch.sigmoid(ref), 2e-5, "dwconv swish")
     out = E.dwconv(_cl(x, dev), pk, act=E.ACT_NONE)
     _close(out.as_ncdhw(C), ref, 2e-5, "dwconv")
-    if k[1] == k[2] and k[2] in (3, 7) and s[2] in (1, 2) and (k[2], s[2]) != (7, 2):
+    if k[1] == k[2] and k[2] in (3, 5, 7) and s[2] in (1, 2) and (k[2], s[2]) not in ((7, 2), (5, 2)):
         out, part = E.dwconv(_cl(x, dev), pk, pool=True, act=E.ACT_NONE)
         _close(out.as_ncdhw(C), ref, 2e-5, "dwconv (pool)")
         _close(part.sum(1)[:, :C], ref.sum((2, 3, 4)), 2e-5, "se pool partial sums")

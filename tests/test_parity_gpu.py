@@ -49,6 +49,18 @@ def test_s3d_backbone_vs_golden(dev, golden_dir):
         assert T.feature_error(f, g, "v%d" % (i + 1)) < 1e-4, "v%d" % (i + 1)
 
 
+@pytest.mark.parametrize("case", ["uniformer_backbone_64", "uniformer_backbone_224"])
+def test_uniformer_backbone_vs_golden(dev, golden_dir, case):
+    from mspi_amd.backbones.uniformer import Uniformer
+    from mspi_amd.config import cfg
+    g = _g(golden_dir, case)
+    m = T.condition_(T.seeded(lambda: Uniformer(cfg.MODEL.UNIFORMER.PATH_CFG), int(g["seed"])), "uniformerb").to(dev)
+    clips, _ = T.synth_inputs(int(g["batch"]), 16, int(g["size"]), int(g["size"]), seed=int(g["seed"]), device=dev)
+    feats = m([clips])
+    for i, f in enumerate(feats):
+        assert T.feature_error(f, g, "v%d" % (i + 1)) < 1e-4, "v%d" % (i + 1)
+
+
 def test_slowfast_backbone_vs_golden(dev, golden_dir):
     from mspi_amd.backbones.sf import SlowFast
     from mspi_amd.config import cfg
@@ -107,14 +119,15 @@ def test_resnet18_audio_vs_golden(dev, golden_dir, wa):
 def _build(g, name, cls, dev):
     from mspi_amd.model import model_utils as pm
     cfg = T.make_cfg(name, num_aud_tokens=int(g["num_aud_tokens"]), num_vis_tokens=int(g["num_vis_tokens"]))
-    m = T.seeded(lambda: getattr(pm, cls)(cfg), int(g["seed"]))
+    m = T.condition_(T.seeded(lambda: getattr(pm, cls)(cfg), int(g["seed"])), name)
     assert T.sd_checksum(m.state_dict()) == int(g["sd_crc"])
     clips, audio = T.synth_inputs(int(g["batch"]), 16, int(g["size"]), int(g["size"]), Wa=int(g["wa"]), seed=int(g["seed"]), device=dev)
     return cfg, m.to(dev), clips, audio
 
 
 @pytest.mark.parametrize("case,name", [("av_x3dl_64", "x3dl"), ("av_x3dl_224", "x3dl"), ("av_slowfast_64", "slowfast4x16"),
-                                       ("av_mvit_224", "mvitv2s"), ("av_swin_s_224", "videoswins"), ("av_s3d_64", "s3d")])
+                                       ("av_mvit_224", "mvitv2s"), ("av_swin_s_224", "videoswins"), ("av_s3d_64", "s3d"),
+                                       ("av_uniformer_64", "uniformerb")])
 def test_audio_visual_model_vs_golden(dev, golden_dir, case, name):
     g = _g(golden_dir, case)
     cfg, m, clips, audio = _build(g, name, "AudioVisualSaliencyModel", dev)
