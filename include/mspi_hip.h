@@ -237,6 +237,13 @@ int mspi_logsumexp_sub(float* x, int32_t N, int32_t L, mspi_stream_t stream);
 int mspi_mean_rows(const float* x, int64_t ldx, int64_t rows_per_sample_stride, float* out, int32_t N,
                    int32_t R, int32_t C, mspi_stream_t stream);
 
+/* The same mean for long samples (MorphFC re-weighting, backbones/MorphMLP.py:62,104: 25088 rows per sample): two
+ * deterministic stages through a caller-owned workspace of N * mspi_mean_rows_slices(R) * C floats.
+ * mspi_mean_rows_slices returns 0 when the one-stage mspi_mean_rows is the right call (R < 1024). */
+int mspi_mean_rows_slices(int32_t R);
+int mspi_mean_rows_ws(const float* x, int64_t ldx, int64_t rows_per_sample_stride, float* out, float* ws, int32_t N,
+                      int32_t R, int32_t C, mspi_stream_t stream);
+
 /* out[0] (+)= scale * mean_n( -cos(p[n,:], z[n,:]) )   (D(), model/model_utils.py:285-290). */
 int mspi_neg_cosine(const float* p, const float* z, float* out, int32_t N, int32_t C, float scale,
                     int32_t accumulate, mspi_stream_t stream);
@@ -304,6 +311,21 @@ int mspi_rowgemm_fwd(const MspiRowGemmDesc* d, const void* x, const void* w_pack
  * ground-truth density, fix the binary fixation map (NULL: NSS is written as 0).  Batch means are the caller's. */
 int mspi_saliency_metrics(const float* pred, const float* gt, const float* fix, float* out /*[N][4]*/, int32_t N, int32_t L,
                           int32_t pred_is_log, mspi_stream_t stream);
+
+/* MorphMLP token regrouping (backbones/MorphMLP.py:49-58,87-100,134-137: the reshape/permute/reshape chains around
+ * mlp_h / mlp_w / mlp_t) as ONE strided gather: y is dense with extents dims[0..5] (dims[5] innermost),
+ * y[i0..i5] = x[sum_k i_k * strides[k]]; strides[5] must be 1, src_elems bounds the reads. */
+typedef struct MspiPermuteDesc {
+  int32_t dims[6];
+  int64_t strides[6];
+  int64_t src_elems;
+} MspiPermuteDesc;
+int mspi_permute_fwd(const MspiPermuteDesc* d, const float* x, float* y, mspi_stream_t stream);
+
+/* MorphFC re-weighting (backbones/MorphMLP.py:64-67,104-107): y[n,r,c] = sum_j softmax_j(logit[n, c*J + j]) * src_j[n,r,c]
+ * over dense [N, rows_per_sample, C] operands; J = 3 (a, b, c) or 2 (a, b; c may be NULL). */
+int mspi_gated_sum_fwd(const float* a, const float* b, const float* c, const float* logit, float* y, int32_t N,
+                       int64_t rows_per_sample, int32_t C, int32_t J, mspi_stream_t stream);
 
 /* y = a + b over n floats (plain residual add where no producer can fuse it). */
 int mspi_add(const float* a, const float* b, float* y, int64_t n, mspi_stream_t stream);

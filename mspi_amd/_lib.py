@@ -84,6 +84,10 @@ class RowGemmDesc(C.Structure):
     ]
 
 
+class PermuteDesc(C.Structure):
+    _fields_ = [("dims", C.c_int32 * 6), ("strides", C.c_int64 * 6), ("src_elems", C.c_int64)]
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -109,8 +113,12 @@ _SIGNATURES = {
     "mspi_rowgate": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, _P]),
     "mspi_logsumexp_sub": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "mspi_mean_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "mspi_mean_rows_slices": (C.c_int, [C.c_int32]),
+    "mspi_mean_rows_ws": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mspi_neg_cosine": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P]),
     "mspi_add": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "mspi_permute_fwd": (C.c_int, [C.POINTER(PermuteDesc), _P, _P, _P]),
+    "mspi_gated_sum_fwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P]),
     "mspi_saliency_metrics": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mspi_rowgemm_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "mspi_rowgemm_supported": (C.c_int, [C.c_int32, C.c_int32]),

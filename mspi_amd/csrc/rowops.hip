@@ -252,6 +252,37 @@ __global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict_
   if (g == 0 && c < C) out[(long)n * C + c] = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) / (float)R;
 }
 
+// Two-stage form for long samples (MorphMLP's re-weighting pools 25088 rows): stage 1 sums `chunk` rows per block into
+// ws[n][slice][C] (grid (ceil(C/64), slices, N)), stage 2 adds the slices in fixed order and scales by 1/R.  No atomics.
+__global__ __launch_bounds__(256) void sum_rows_slice_kernel(const float* __restrict__ x, long ldx, long sample_stride,
+                                                             float* __restrict__ ws, int R, int C, int chunk) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  const int n = blockIdx.z;
+  const int r0 = blockIdx.y * chunk, r1 = min(R, r0 + chunk);
+  float s = 0.f;
+  if (c < C) {
+    const float* b = x + (long)n * sample_stride + c;
+    for (int r = r0 + g; r < r1; r += 4) s += b[(long)r * ldx];
+  }
+  part[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0 && c < C)
+    ws[((long)n * gridDim.y + blockIdx.y) * C + c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict__ ws, float* __restrict__ out, int S, int C,
+                                                         float inv, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const long n = idx / C;
+  const int c = (int)(idx - n * C);
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += ws[(n * S + k) * C + c];
+  out[idx] = s * inv;
+}
+
 // out (+)= scale * mean_n( -cos(p_n, z_n) ), F.cosine_similarity eps = 1e-8 on each norm
 __global__ __launch_bounds__(256) void neg_cosine_kernel(const float* __restrict__ p, const float* __restrict__ z,
                                                          float* __restrict__ out, int N, int C, float scale,
@@ -383,6 +414,21 @@ extern "C" int mspi_mean_rows(const float* x, int64_t ldx, int64_t sample_stride
   hipLaunchKernelGGL(mean_rows_kernel, dim3((C + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
                      (long)sample_stride, out, R, C);
   return check_launch("mspi_mean_rows");
+}
+
+extern "C" int mspi_mean_rows_slices(int32_t R) { return R >= 1024 ? (R + 255) / 256 : 0; }
+
+extern "C" int mspi_mean_rows_ws(const float* x, int64_t ldx, int64_t sample_stride, float* out, float* ws, int32_t N,
+                                 int32_t R, int32_t C, mspi_stream_t stream) {
+  MSPI_REQUIRE(x && out && ws && N > 0 && R > 0 && C > 0 && N < 65536, "mspi_mean_rows_ws: bad argument");
+  const int S = mspi_mean_rows_slices(R);
+  MSPI_REQUIRE(S > 0 && S < 65536, "mspi_mean_rows_ws: R=%d is served by mspi_mean_rows (no workspace)", R);
+  hipLaunchKernelGGL(sum_rows_slice_kernel, dim3((C + 63) / 64, S, N), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
+                     (long)sample_stride, ws, R, C, 256);
+  const long total = (long)N * C;
+  hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, out, S, C,
+                     1.f / (float)R, total);
+  return check_launch("mspi_mean_rows_ws");
 }
 
 extern "C" int mspi_neg_cosine(const float* p, const float* z, float* out, int32_t N, int32_t C, float scale,

@@ -747,7 +747,12 @@ def mean_rows(x, N, R, out):
     """x: CL with R = T*H*W rows per sample (token slabs allowed); out [N, C] tensor."""
     lib = _lib.load()
     assert x.N == N and x.T * x.H * x.W == R
-    check(lib.mspi_mean_rows(x.ptr, x.ld, x.sN, out.data_ptr(), N, R, x.C, _stream()), "mspi_mean_rows")
+    S = lib.mspi_mean_rows_slices(R)
+    if S:      # long samples: two deterministic stages through a workspace (stream-ordered: safe to drop after the launch)
+        ws = torch.empty(N * S * x.C, dtype=torch.float32, device=x.buf.device)
+        check(lib.mspi_mean_rows_ws(x.ptr, x.ld, x.sN, out.data_ptr(), ws.data_ptr(), N, R, x.C, _stream()), "mspi_mean_rows_ws")
+    else:
+        check(lib.mspi_mean_rows(x.ptr, x.ld, x.sN, out.data_ptr(), N, R, x.C, _stream()), "mspi_mean_rows")
     return out
 
 
@@ -763,6 +768,51 @@ def add(a, b, y):
     lib = _lib.load()
     check(lib.mspi_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "mspi_add")
     return y
+
+
+def permute(src, dims, strides, out=None):
+    """Strided gather (mspi_permute_fwd): dense fp32 tensor of shape `dims` (<= 6, innermost contiguous on both sides)
+    with out[i0..] = src.flat[sum_k i_k * strides[k]].  src: a CL (its buffer from .ptr on) or a flat torch tensor."""
+    lib = _lib.load()
+    if isinstance(src, CL):
+        _need_gpu(src.buf)
+        ptr, n_src, dev = src.ptr, src.buf.numel() - src.off, src.buf.device
+    else:
+        _need_gpu(src)
+        ptr, n_src, dev = src.data_ptr(), src.numel(), src.device
+    dims, strides = list(dims), list(strides)
+    assert len(dims) == len(strides) <= 6
+    pad = 6 - len(dims)
+    d = _lib.PermuteDesc()
+    d.dims[:] = [1] * pad + dims
+    d.strides[:] = [0] * pad + strides
+    d.src_elems = n_src
+    n = 1
+    for v in dims:
+        n *= v
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+    assert out.numel() == n
+    with _Timed("permute", 0.0, 8.0 * n):
+        check(lib.mspi_permute_fwd(C.byref(d), ptr, out.data_ptr(), _stream()), "mspi_permute_fwd")
+    return out
+
+
+def gated_sum(srcs, logit, out=None):
+    """sum_j softmax_j(logit[n, c*J+j]) * srcs[j][n,r,c] over dense CLs of one shape (J = len(srcs) in {2, 3})."""
+    lib = _lib.load()
+    a = srcs[0]
+    for s_ in srcs:
+        _need_gpu(s_.buf)
+        assert s_.dense and s_.ld == a.C and (s_.N, s_.M, s_.C) == (a.N, a.M, a.C)
+    if out is None:
+        out = alloc(a.N, a.T, a.H, a.W, a.C, a.buf.device)
+    J = len(srcs)
+    assert logit.shape == (a.N, a.C * J) and logit.is_contiguous() and out.ld == a.C
+    with _Timed("gated_sum", 0.0, 4.0 * (J + 1) * a.M * a.C):
+        check(lib.mspi_gated_sum_fwd(srcs[0].ptr, srcs[1].ptr, srcs[2].ptr if J == 3 else None, logit.data_ptr(), out.ptr,
+                                     a.N, a.M // a.N, a.C, J, _stream()), "mspi_gated_sum_fwd")
+    return out
 
 
 def postprocess_u8(logmap, out_hw):

@@ -29,7 +29,8 @@ def video_motion_extractor(cfg):
         from ..backbones.uniformer import Uniformer
         motion_encoder = Uniformer(yaml_path=cfg.MODEL.UNIFORMER.PATH_CFG)
     elif name == "morphmlps":
-        raise NotImplementedError("motion encoder %r is outside the MI355X hot-path scope (SURVEY.md section 8f)" % name)
+        from ..backbones.MorphMLP import MorphMLP_32_features_only
+        motion_encoder = MorphMLP_32_features_only(path_to_config=cfg.MODEL.MORPH.PATH_CFG)
     if motion_encoder is None:
         raise Exception("Invalid Motion Encoder!")
     return motion_encoder

@@ -503,7 +503,7 @@ class _SaliencyBase(HipModule):
         name = self.cfg.MODEL.MOTION_ENCODER
         if name == "slowfast4x16":  # model/model_utils.py:521-524: slow pathway = frames 0, 4, 12, last
             return [torch.stack([clips[:, :, 0], clips[:, :, 4], clips[:, :, 12], clips[:, :, -1]], dim=2), clips]
-        if "swin" in name or name == "s3d":
+        if "swin" in name or "morph" in name or name == "s3d":
             return clips
         return [clips]
 

@@ -62,8 +62,11 @@ def build_reference_model(name, cls_name, num_vis_tokens=None):
     import model.model_utils as mu
     import backbones.sf as ref_sf
     import backbones.s3d as ref_s3d
+    import backbones.MorphMLP as ref_morph
     real_load, real_lsd, real_sf_lw = torch.load, nn.Module.load_state_dict, ref_sf.SlowFast.load_weight
     real_s3d_lw = ref_s3d.S3D_features_only.load_weight
+    real_morph_lw = ref_morph.MorphMLP_32_features_only.load_weight
+    ref_morph.MorphMLP_32_features_only.load_weight = lambda self, path: None   # deletes head.* from the (absent) checkpoint
     ref_sf.SlowFast.load_weight = lambda self, path: None    # caffe2 .pkl loader opens the (absent) file itself
     ref_s3d.S3D_features_only.load_weight = lambda self, path: None   # raises on the absent file before any torch.load
     torch.load = lambda *a, **k: _NoWeights()
@@ -73,6 +76,7 @@ def build_reference_model(name, cls_name, num_vis_tokens=None):
     finally:
         torch.load, nn.Module.load_state_dict, ref_sf.SlowFast.load_weight = real_load, real_lsd, real_sf_lw
         ref_s3d.S3D_features_only.load_weight = real_s3d_lw
+        ref_morph.MorphMLP_32_features_only.load_weight = real_morph_lw
     return m.eval()
 
 
@@ -330,6 +334,31 @@ def case_uniformer_backbone(seed=0):
 
 def case_av_uniformer_64():
     _model_case("uniformerb", "AudioVisualSaliencyModel", 64, 2, 111, 0, "av_uniformer_64")
+
+
+def case_morphmlp_backbone(seed=0):
+    """MorphMLP_32_features_only (backbones/MorphMLP.py:371-519, MorphMLP-S per configs/K400_MLP_S16x4.yaml) with the
+    product's seeded state dict, strict load.  224x224 only: upstream's reshapes need H*W of every stage to be a
+    multiple of its segment_dim (14, 28, 28, 49)."""
+    from mspi_amd.backbones.MorphMLP import MorphMLP_32_features_only
+    from mspi_amd.config import cfg as pcfg
+    prod = T.seeded(lambda: MorphMLP_32_features_only(pcfg.MODEL.MORPH.PATH_CFG), seed)
+    sd = prod.state_dict()
+    rcfg = rh.with_config("morphmlps")
+    from backbones.MorphMLP import MorphMLP_32_features_only as RefMorph
+    ref = RefMorph(path_to_config=rcfg.MODEL.MORPH.PATH_CFG).eval()
+    ref.load_state_dict(sd, strict=True)
+    clips, _ = T.synth_inputs(1, 16, 224, 224, seed=seed)
+    with torch.no_grad():
+        feats = ref(clips)
+        ora = R.morphmlp_forward(sd, clips)
+    scale = max(f.abs().max().item() for f in feats)
+    _check_restatement("morphmlp-S backbone 224 (abs-max %.1f)" % scale, feats, ora, 2e-5 * max(scale, 1.0))
+    _save("morphmlp_backbone_224", seed=seed, size=224, batch=1, sd_crc=T.sd_checksum(sd), **_feat_fixture(feats))
+
+
+def case_av_morphmlp_224():
+    _model_case("morphmlps", "AudioVisualSaliencyModel", 224, 1, 111, 0, "av_morphmlp_224")
 
 
 def c2_name_corpus():

@@ -499,7 +499,7 @@ def pack_clips(name, clips):
     """model/model_utils.py:521-532: SlowFast slow pathway = frames [0,4,12,-1] (F7)."""
     if name == "slowfast4x16":
         return [torch.stack([clips[:, :, 0], clips[:, :, 4], clips[:, :, 12], clips[:, :, -1]], 2), clips]
-    if name in ("videoswins", "s3d"):
+    if name in ("videoswins", "s3d", "morphmlps"):
         return clips
     return [clips]
 
@@ -593,11 +593,80 @@ def uniformer_forward(sd, clips, prefix="", head_dim=64):
     return feats
 
 
+# ------------------------------------------------------------------------------- MorphMLP-S
+def _morph_mlp(sd, p, x):
+    return _lin(sd, p + ".fc2", F.gelu(_lin(sd, p + ".fc1", x)))
+
+
+def morph_fc_t(sd, p, x):
+    """MorphFC_T, backbones/MorphMLP.py:116-158: Linear over (frame, 1/8 channel slice), segment_dim fixed to 8."""
+    B, T, H, W, C = x.shape
+    S = C // 8
+    t = x.reshape(B, T, H, W, 8, S).permute(0, 4, 2, 3, 1, 5).reshape(B, 8, H, W, T * S)
+    t = _lin(sd, p + ".mlp_t", t).reshape(B, 8, H, W, T, S).permute(0, 4, 2, 3, 1, 5).reshape(B, T, H, W, C)
+    return _lin(sd, p + ".proj", t)
+
+
+def morph_fc_s(sd, p, x, seg):
+    """MorphFC_S, backbones/MorphMLP.py:71-113: Linears over chunks of `seg` positions along H / along W / channels,
+    mixed by softmax(reweight(mean(h + w + c)))."""
+    B, T, H, W, C = x.shape
+    S, n = C // seg, H * W // seg
+    h = x.transpose(3, 2).reshape(B, T, n, seg, seg, S).permute(0, 1, 2, 4, 3, 5).reshape(B, T, n, seg, seg * S)
+    h = _lin(sd, p + ".mlp_h", h).reshape(B, T, n, seg, seg, S).permute(0, 1, 2, 4, 3, 5).reshape(B, T, W, H, C).transpose(3, 2)
+    w = x.reshape(B, T, n, seg, seg, S).permute(0, 1, 2, 4, 3, 5).reshape(B, T, n, seg, seg * S)
+    w = _lin(sd, p + ".mlp_w", w).reshape(B, T, n, seg, seg, S).permute(0, 1, 2, 4, 3, 5).reshape(B, T, H, W, C)
+    c = _lin(sd, p + ".mlp_c", x)
+    a = (h + w + c).permute(0, 4, 1, 2, 3).flatten(2).mean(2)
+    a = _morph_mlp(sd, p + ".reweight", a).reshape(B, C, 3).permute(2, 0, 1).softmax(dim=0)[:, :, None, None, None]
+    return _lin(sd, p + ".proj", h * a[0] + w * a[1] + c * a[2])
+
+
+def morph_fc_s2(sd, p, x, seg):
+    """MorphFC_S2, backbones/MorphMLP.py:38-68 (last stage): one spatial Linear + the channel Linear."""
+    B, T, H, W, C = x.shape
+    S, n = C // seg, H * W // seg
+    h = x.reshape(B, T, seg, n, seg, S).permute(0, 1, 4, 3, 2, 5).reshape(B, T, seg, n, seg * S)
+    h = _lin(sd, p + ".mlp_h", h).reshape(B, T, seg, n, seg, S).permute(0, 1, 4, 3, 2, 5).reshape(B, T, H, W, C)
+    c = _lin(sd, p + ".mlp_c", x)
+    a = (h + c).permute(0, 4, 1, 2, 3).flatten(2).mean(2)
+    a = _morph_mlp(sd, p + ".reweight", a).reshape(B, C, 2).permute(2, 0, 1).softmax(dim=0)[:, :, None, None, None]
+    return _lin(sd, p + ".proj", h * a[0] + c * a[1])
+
+
+def morph_block(sd, p, x, seg, last):
+    """PermutatorBlock, backbones/MorphMLP.py:161-187 (skip_lam 1): note the second shortcut starts from x, not xt."""
+    xt = x + morph_fc_t(sd, p + ".t_fc", _ln(sd, p + ".t_norm1", x))
+    fc = morph_fc_s2 if last else morph_fc_s
+    x = x + fc(sd, p + ".fc", _ln(sd, p + ".norm1", xt), seg)
+    return x + _morph_mlp(sd, p + ".mlp", _ln(sd, p + ".norm2", x))
+
+
+def morphmlp_forward(sd, clips, prefix="", segment_dim=(14, 28, 28, 49)):
+    """MorphMLP_32_features_only.forward_features, backbones/MorphMLP.py:480-503 -> four NCDHW stage outputs."""
+    p = prefix
+    x = F.gelu(_bn(sd, p + "patch_embed1.norm1", _conv3(sd, p + "patch_embed1.proj1", clips, 2, 1), 1e-5))
+    x = _bn(sd, p + "patch_embed1.norm2", _conv3(sd, p + "patch_embed1.proj2", x, (1, 2, 2), (0, 1, 1)), 1e-5)
+    x = x.permute(0, 2, 3, 4, 1)
+    feats = []
+    for s in range(1, 5):
+        if s > 1:                                                               # Downsample :211-225
+            x = _conv3(sd, p + "patch_embed%d.proj" % s, x.permute(0, 4, 1, 2, 3), (1, 2, 2), (0, 1, 1))
+            x = _ln(sd, p + "patch_embed%d.norm" % s, x.permute(0, 2, 3, 4, 1))
+        i = 0
+        while p + "blocks%d.%d.norm1.weight" % (s, i) in sd:
+            x = morph_block(sd, p + "blocks%d.%d" % (s, i), x, segment_dim[s - 1], s == 4)
+            i += 1
+        feats.append(x.permute(0, 4, 1, 2, 3))
+    return feats
+
+
 BACKBONES = {}  # name -> fn(sd, packed_clips, prefix) -> [v1..v4]; filled below and by restate_tx.py
 BACKBONES["x3dl"] = lambda sd, x, prefix: x3d_forward(sd, x[0], prefix)
 BACKBONES["slowfast4x16"] = lambda sd, x, prefix: slowfast_forward(sd, x, prefix)
 BACKBONES["s3d"] = lambda sd, x, prefix: s3d_forward(sd, x, prefix)
 BACKBONES["uniformerb"] = lambda sd, x, prefix: uniformer_forward(sd, x[0], prefix)
+BACKBONES["morphmlps"] = lambda sd, x, prefix: morphmlp_forward(sd, x, prefix)
 MVIT_S_ARCH = {   # configs/MVITv2_S_16x4.yaml resolved the way MViT.__init__ does (backbones/MViT.py:1779-1826)
     "patch_stride": (2, 4, 4), "patch_padding": (1, 3, 3),
     "blocks": [(1, (1, 1, 1), (1, 8, 8)), (2, (1, 2, 2), (1, 4, 4)), (2, (1, 1, 1), (1, 4, 4)), (4, (1, 2, 2), (1, 2, 2))]

@@ -239,5 +239,55 @@ def test_uniformer_factory_and_keys():
     assert {"patch_embed1.proj.weight", "patch_embed1.norm.bias", "blocks1.4.attn.weight", "blocks2.7.mlp.fc2.bias",
             "blocks3.19.attn.qkv.bias", "blocks4.6.mlp.fc1.weight", "norm.running_var", "head.weight"} <= keys
     assert m.blocks1[0].attn.weight.shape == (64, 1, 5, 5, 5) and m.blocks3[0].attn.qkv.weight.shape == (960, 320)
-    with pytest.raises(NotImplementedError):
-        video_motion_extractor(T.make_cfg("morphmlps"))
+
+
+def _strided(src, dims, strides):
+    return src.reshape(-1).as_strided(tuple(dims), tuple(strides))
+
+
+@pytest.mark.parametrize("H,W,C,sd", [(56, 56, 112, 14), (28, 28, 224, 28), (14, 14, 392, 28), (28, 14, 56, 14), (7, 14, 56, 14)])
+def test_morph_regroupings_match_reference_expressions(H, W, C, sd):
+    """The (dims, strides) gathers of mspi_amd.backbones.MorphMLP against the reference's reshape/permute chains
+    (backbones/MorphMLP.py:84-102 for MorphFC_S, :134-137 for MorphFC_T), evaluated with as_strided on the host."""
+    from mspi_amd.backbones import MorphMLP as M
+    B, T, S = 2, 8, C // sd
+    x = torch.arange(B * T * H * W * C, dtype=torch.float32).reshape(B, T, H, W, C)
+    n = H * W // sd
+    # W branch
+    w = x.reshape(B, T, n, sd, sd, S).permute(0, 1, 2, 4, 3, 5).reshape(B, T, n, sd, sd * S)
+    assert torch.equal(_strided(x, *M.w_gather(B * T, H * W, C, sd)).reshape(w.shape), w)
+    back = w.reshape(B, T, n, sd, sd, S).permute(0, 1, 2, 4, 3, 5).reshape(B, T, H, W, C)
+    assert torch.equal(_strided(w.contiguous(), *M.w_scatter(B * T, H * W, C, sd)).reshape(x.shape), back) and torch.equal(back, x)
+    # H branch (transposed grid)
+    h = x.transpose(3, 2).reshape(B, T, n, sd, sd, S).permute(0, 1, 2, 4, 3, 5).reshape(B, T, n, sd, sd * S)
+    assert torch.equal(_strided(x, *M.h_gather(B * T, H, W, C, sd)).reshape(h.shape), h)
+    back = h.reshape(B, T, n, sd, sd, S).permute(0, 1, 2, 4, 3, 5).reshape(B, T, W, H, C).transpose(3, 2)
+    assert torch.equal(_strided(h.contiguous(), *M.h_scatter(B * T, H, W, C, sd)).reshape(x.shape), back) and torch.equal(back, x)
+    # T branch
+    St = C // 8
+    t = x.reshape(B, T, H, W, 8, St).permute(0, 4, 2, 3, 1, 5).reshape(B, 8, H, W, T * St)
+    assert torch.equal(_strided(x, *M.t_gather(B, T, H * W, C)).reshape(t.shape), t)
+    back = t.reshape(B, 8, H, W, T, St).permute(0, 4, 2, 3, 1, 5).reshape(B, T, H, W, C)
+    assert torch.equal(_strided(t.contiguous(), *M.t_scatter(B, T, H * W, C)).reshape(x.shape), back)
+
+
+@pytest.mark.parametrize("H,W,C,sd", [(7, 7, 784, 49), (14, 7, 98, 49)])
+def test_morph_s2_regrouping(H, W, C, sd):
+    """MorphFC_S2 (backbones/MorphMLP.py:49-58)."""
+    from mspi_amd.backbones import MorphMLP as M
+    B, T, S, n = 1, 8, C // sd, H * W // sd
+    x = torch.arange(B * T * H * W * C, dtype=torch.float32).reshape(B, T, H, W, C)
+    h = x.reshape(B, T, sd, n, sd, S).permute(0, 1, 4, 3, 2, 5).reshape(B, T, sd, n, sd * S)
+    assert torch.equal(_strided(x, *M.s2_gather(B * T, H * W, C, sd)).reshape(h.shape), h)
+    back = h.reshape(B, T, sd, n, sd, S).permute(0, 1, 4, 3, 2, 5).reshape(B, T, H, W, C)
+    assert torch.equal(_strided(h.contiguous(), *M.s2_scatter(B * T, H * W, C, sd)).reshape(x.shape), back)
+
+
+def test_morphmlp_factory_and_keys():
+    from mspi_amd import testing as T
+    from mspi_amd.model.get_video_backbones import video_motion_extractor
+    m = video_motion_extractor(T.make_cfg("morphmlps"))
+    keys = set(m.state_dict())
+    assert {"patch_embed1.proj1.weight", "patch_embed1.norm2.running_var", "patch_embed4.norm.bias", "blocks1.2.t_fc.mlp_t.bias",
+            "blocks3.8.fc.mlp_w.weight", "blocks3.0.fc.reweight.fc2.bias", "blocks4.2.fc.mlp_h.weight", "blocks2.3.mlp.fc1.weight"} <= keys
+    assert "blocks4.0.fc.mlp_w.weight" not in keys and m.blocks4[0].fc.reweight.fc2.out_features == 2 * 784

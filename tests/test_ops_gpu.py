@@ -363,6 +363,10 @@ def test_small_reductions(dev):
     out = torch.empty(2, 512, device=dev)
     E.mean_rows(sc.tokens(7, 5, 2, 3), 2, 30, out)
     _close(out, seq[:, 7:37].mean(1), 1e-5, "mean_rows")
+    long = torch.randn(3, 3001, 100, generator=g) + 0.5            # two-stage form (R >= 1024), ragged last slice
+    out = torch.empty(3, 100, device=dev)
+    E.mean_rows(E.CL(long.to(dev).view(-1), 0, 3, 3001, 1, 1, 100, 100), 3, 3001, out)
+    _close(out, long.mean(1), 1e-6, "mean_rows (two-stage)")
     p, z = torch.randn(4, 2048, generator=g), torch.randn(4, 2048, generator=g)
     loss = torch.zeros(1, device=dev)
     E.neg_cosine(E.from_rows(p.to(dev)), E.from_rows(z.to(dev)), loss, 0.5, False)
@@ -501,3 +505,33 @@ def test_conv_split_k(dev, S, shape):
     _close(out.as_ncdhw(Cout), ref, 2e-5, "split-K %d %s" % (S, shape))
     out2 = E.conv(_cl(x, dev), pk, res=_cl(res, dev), tile=E.SPLITK + S)
     assert torch.equal(out.buf, out2.buf)
+
+
+def test_permute_and_gated_sum(dev):
+    """mspi_permute_fwd against as_strided (vector and scalar paths) and mspi_gated_sum_fwd against torch (J = 2, 3)."""
+    from mspi_amd import engine as E
+    from mspi_amd._lib import MspiError
+    from mspi_amd.backbones import MorphMLP as M
+    g = torch.Generator().manual_seed(5)
+    for (H, W, Cc, sd) in ((28, 14, 56, 14), (14, 14, 392, 28), (7, 7, 98, 49)):
+        B, T = 2, 8
+        x = torch.randn(B, T, H, W, Cc, generator=g)
+        xd = x.to(dev)
+        specs = [M.t_gather(B, T, H * W, Cc), M.t_scatter(B, T, H * W, Cc), M.w_gather(B * T, H * W, Cc, sd),
+                 M.s2_gather(B * T, H * W, Cc, sd), M.s2_scatter(B * T, H * W, Cc, sd)]
+        if H % sd == 0 or sd % H == 0:
+            specs += [M.h_gather(B * T, H, W, Cc, sd), M.h_scatter(B * T, H, W, Cc, sd)]
+        for dims, strides in specs:
+            got = E.permute(xd.reshape(-1), dims, strides).cpu()
+            assert torch.equal(got, x.reshape(-1).as_strided(tuple(dims), tuple(strides)).reshape(-1))
+    with pytest.raises(MspiError, match="source"):
+        E.permute(xd.reshape(-1), (4, xd.numel()), (1, 1))
+    N, R, Cc = 3, 50, 56
+    srcs = [torch.randn(N, R, Cc, generator=g) for _ in range(3)]
+    for J in (2, 3):
+        logit = torch.randn(N, Cc * J, generator=g) * 2
+        a = logit.reshape(N, Cc, J).permute(2, 0, 1).softmax(0)[:, :, None, :]
+        ref = sum(a[j] * srcs[j] for j in range(J))
+        cls = [E.CL(s_.to(dev).reshape(-1), 0, N, 1, R, 1, Cc, Cc) for s_ in srcs[:J]]
+        out = E.gated_sum(cls, logit.to(dev))
+        _close(out.buf.view(N, R, Cc), ref, 1e-6, "gated_sum J=%d" % J)

@@ -75,6 +75,24 @@ def test_uniformer_backbone(golden_dir, case):
         assert T.feature_error(f, g, "v%d" % (i + 1)) <= 1e-6
 
 
+def test_morphmlp_backbone(golden_dir):
+    """MorphMLP_32_features_only (MorphMLP-S); fixture = the reference's own forward at 224x224 (the only
+    extent upstream's reshapes accept).  The reference's permuted views take other matmul paths than the restatement's
+    contiguous ones: equal to 1e-6 of the feature scale, not bit for bit."""
+    from mspi_amd.backbones.MorphMLP import MorphMLP_32_features_only
+    from mspi_amd.config import cfg
+    g = _g(golden_dir, "morphmlp_backbone_224")
+    m = T.seeded(lambda: MorphMLP_32_features_only(cfg.MODEL.MORPH.PATH_CFG), int(g["seed"]))
+    sd = m.state_dict()
+    assert T.sd_checksum(sd) == int(g["sd_crc"])
+    clips, _ = T.synth_inputs(int(g["batch"]), 16, int(g["size"]), int(g["size"]), seed=int(g["seed"]))
+    with torch.no_grad():
+        feats = R.morphmlp_forward(sd, clips)
+    assert [f.shape[1] for f in feats] == [112, 224, 392, 784]
+    for i, f in enumerate(feats):
+        assert T.feature_error(f, g, "v%d" % (i + 1)) <= 5e-6
+
+
 def test_slowfast_backbone(golden_dir):
     from mspi_amd.backbones.sf import SlowFast
     from mspi_amd.config import cfg
@@ -181,7 +199,7 @@ def _model(g, name, cls):
 
 @pytest.mark.parametrize("case,name", [("av_x3dl_64", "x3dl"), ("av_x3dl_224", "x3dl"), ("av_slowfast_64", "slowfast4x16"),
                                        ("av_mvit_224", "mvitv2s"), ("av_swin_s_224", "videoswins"), ("av_s3d_64", "s3d"),
-                                       ("av_uniformer_64", "uniformerb")])
+                                       ("av_uniformer_64", "uniformerb"), ("av_morphmlp_224", "morphmlps")])
 def test_audio_visual_model(golden_dir, case, name):
     g = _g(golden_dir, case)
     cfg, sd, clips, audio = _model(g, name, "AudioVisualSaliencyModel")

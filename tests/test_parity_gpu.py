@@ -61,6 +61,17 @@ def test_uniformer_backbone_vs_golden(dev, golden_dir, case):
         assert T.feature_error(f, g, "v%d" % (i + 1)) < 1e-4, "v%d" % (i + 1)
 
 
+def test_morphmlp_backbone_vs_golden(dev, golden_dir):
+    from mspi_amd.backbones.MorphMLP import MorphMLP_32_features_only
+    from mspi_amd.config import cfg
+    g = _g(golden_dir, "morphmlp_backbone_224")
+    m = T.seeded(lambda: MorphMLP_32_features_only(cfg.MODEL.MORPH.PATH_CFG), int(g["seed"])).to(dev)
+    clips, _ = T.synth_inputs(int(g["batch"]), 16, int(g["size"]), int(g["size"]), seed=int(g["seed"]), device=dev)
+    feats = m(clips)
+    for i, f in enumerate(feats):
+        assert T.feature_error(f, g, "v%d" % (i + 1)) < 1e-4, "v%d" % (i + 1)
+
+
 def test_slowfast_backbone_vs_golden(dev, golden_dir):
     from mspi_amd.backbones.sf import SlowFast
     from mspi_amd.config import cfg
@@ -127,7 +138,7 @@ def _build(g, name, cls, dev):
 
 @pytest.mark.parametrize("case,name", [("av_x3dl_64", "x3dl"), ("av_x3dl_224", "x3dl"), ("av_slowfast_64", "slowfast4x16"),
                                        ("av_mvit_224", "mvitv2s"), ("av_swin_s_224", "videoswins"), ("av_s3d_64", "s3d"),
-                                       ("av_uniformer_64", "uniformerb")])
+                                       ("av_uniformer_64", "uniformerb"), ("av_morphmlp_224", "morphmlps")])
 def test_audio_visual_model_vs_golden(dev, golden_dir, case, name):
     g = _g(golden_dir, case)
     cfg, m, clips, audio = _build(g, name, "AudioVisualSaliencyModel", dev)
