@@ -327,6 +327,24 @@ int mspi_permute_fwd(const MspiPermuteDesc* d, const float* x, float* y, mspi_st
 int mspi_gated_sum_fwd(const float* a, const float* b, const float* c, const float* logit, float* y, int32_t N,
                        int64_t rows_per_sample, int32_t C, int32_t J, mspi_stream_t stream);
 
+/* Log-spectrogram windows of the clip loop (inference.py:24-63: torchaudio Spectrogram(n_fft=512, hop_length=160) on
+ * audio[start:end] (optionally time-reversed), log(p + 1e-6), per-column standardisation over the 257 bins with the
+ * unbiased std, crop / pad with 0.02 to Wa columns).  wave: 16 kHz mono samples on the device; seg [B][3] =
+ * (start, length, reversed) on the device, seg_host the same table on the host (bounds are validated before the launch);
+ * window: 512 Hann coefficients on the device; out [B][257][Wa]. */
+int mspi_logspec_fwd(const float* wave, int64_t n_wave, const int32_t* seg, const int32_t* seg_host, int32_t B,
+                     const float* window, float* out, int32_t Wa, mspi_stream_t stream);
+
+/* Frame pre-processing (inference.py:154-165: torchvision Resize on a PIL image = PIL's antialiased bilinear resampling,
+ * ToTensor, Normalize).  rgb: uint8 [Hin][Win][3] on the device; tmp: Hin*Wout*3 bytes of device scratch; out: fp32
+ * [3][Hout][Wout] planes `out_plane_stride` floats apart.  hb/vb: [n][2] = (first input index, taps) per output
+ * column / row, hk/vk: [n][hks|vks] 22-bit fixed-point taps -- PIL's precompute_coeffs + normalize_coeffs_8bpc tables,
+ * built by the caller (mspi_amd/preproc.py) and resident on the device; mean3/std3: host floats. */
+int mspi_resize_norm_fwd(const unsigned char* rgb, int32_t Hin, int32_t Win, unsigned char* tmp, float* out,
+                         int64_t out_plane_stride, int32_t Hout, int32_t Wout, const int32_t* hb, const int32_t* hk,
+                         int32_t hks, const int32_t* vb, const int32_t* vk, int32_t vks, const float* mean3_host,
+                         const float* std3_host, mspi_stream_t stream);
+
 /* y = a + b over n floats (plain residual add where no producer can fuse it). */
 int mspi_add(const float* a, const float* b, float* y, int64_t n, mspi_stream_t stream);
 

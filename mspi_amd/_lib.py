@@ -119,6 +119,9 @@ _SIGNATURES = {
     "mspi_add": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "mspi_permute_fwd": (C.c_int, [C.POINTER(PermuteDesc), _P, _P, _P]),
     "mspi_gated_sum_fwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P]),
+    "mspi_logspec_fwd": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int32, _P, _P, C.c_int32, _P]),
+    "mspi_resize_norm_fwd": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32,
+                                        _P, _P, C.c_int32, _P, _P, _P]),
     "mspi_saliency_metrics": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mspi_rowgemm_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "mspi_rowgemm_supported": (C.c_int, [C.c_int32, C.c_int32]),

@@ -5,7 +5,10 @@ flags, same output files `save_path/<video>/<frame name>`; what differs:
   * the model forward and the map post-processing (blur -> exp -> resize -> min-max -> uint8) run on the GPU
     through the C ABI; one uint8 map comes back per frame instead of an fp32 map + five OpenCV passes;
   * sliding windows are independent, so `--batch` windows go through one forward;
-  * the wav is read and resampled once per video, not once per frame (inference.py:28-31 does it per window);
+  * the wav is read and resampled once per video, not once per frame (inference.py:28-31 does it per window), lives on
+    the GPU, and the log-spectrogram windows of a batch are ONE kernel launch (`preproc.log_spectrogram`);
+  * frames are decoded on the host (PIL) and resized + normalised on the GPU with PIL's own fixed-point bilinear
+    resampling (`preproc.resize_normalize`, bit-exact to PIL.Image.resize);
   * videos are sharded over ranks when launched with torch.distributed.run (one process per GPU, no collective);
   * cv2 / torchaudio / torchvision are not required: PIL does the frame decode + resize (what torchvision's
     transforms do on PIL images), scipy reads the wav, and torchaudio's sinc resampler and Spectrogram are
@@ -77,8 +80,24 @@ def _load_wav_16k(audio_path):
     return _AUDIO_CACHE[audio_path]
 
 
+def audio_segment(n_samples, start_idx, fps, len_snippet=32, num_frames=None):
+    """(start, length) in 16 kHz samples of the window that get_audio_feature cuts for the clip starting at frame
+    `start_idx` (inference.py:33-41; python slicing clips the end to the wave).  Windows of 256 samples or fewer cannot be
+    reflect-padded (upstream's Spectrogram raises on them): they are reported as empty = "no audio" (0.02 fill)."""
+    mm = 16000
+    if num_frames is not None:
+        start = int(np.round((start_idx / num_frames * n_samples)))
+        end = int(np.round(((start_idx + len_snippet + 1) / num_frames * n_samples)))
+    else:
+        start = int(np.round((start_idx / float(fps)) * mm))
+        end = int(np.round(((start_idx + len_snippet + 1) / float(fps)) * mm))
+    start, end = min(max(start, 0), n_samples), min(max(end, 0), n_samples)
+    return (start, end - start) if end - start > 256 else (0, 0)
+
+
 def get_audio_feature(audio_path, start_idx, fps, len_snippet=32, mode=False, num_frames=None):
-    """Log-spectrogram window [1,257,111] for the clip starting at frame `start_idx` (inference.py:24-63)."""
+    """Log-spectrogram window [1,257,111] for the clip starting at frame `start_idx` (inference.py:24-63).  Host form with
+    the reference's signature; the clip loop uses the batched GPU form (`preproc.log_spectrogram`) instead."""
     spectro_shape = (257, 111)
     if os.path.exists(audio_path):
         audio = _load_wav_16k(audio_path)
@@ -143,20 +162,27 @@ def process(model, frames, frame_idx, vname, img_size, audio_feature=None, args=
 def torch_transform(path):
     """Resize to the model resolution, scale to [0,1], ImageNet-normalise (inference.py:154-165)."""
     from PIL import Image
+    from . import preproc
     img = Image.open(path).convert("RGB")
     sz = img.size
-    img = img.resize((_RESOLUTION[1], _RESOLUTION[0]), Image.BILINEAR)
-    t = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
-    mean = torch.tensor(IMAGENET_DEFAULT_MEAN).view(3, 1, 1)
-    std = torch.tensor(IMAGENET_DEFAULT_STD).view(3, 1, 1)
-    return (t - mean) / std, sz
+    rgb = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).to(device, non_blocking=True)     # decode on the host,
+    t = preproc.resize_normalize(rgb, (_RESOLUTION[0], _RESOLUTION[1]), IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD)
+    return t, sz                                                       # resize + ToTensor + Normalize on the GPU
 
 
 def _flush(model, batch, vname, img_size, args, feats=None):
     if not batch:
         return
     clips = torch.stack([b[0] for b in batch])
-    auds = torch.stack([b[1] for b in batch])
+    if torch.is_tensor(batch[0][1]):
+        auds = torch.stack([b[1] for b in batch])
+    else:                                   # (start, length, reversed) windows of the video's wave: one launch for the batch
+        from . import preproc
+        wave = batch[0][4]
+        if wave is None:                    # no wav file: the constant the reference feeds (inference.py:60-61)
+            auds = torch.full((len(batch), 1, 257, 111), 0.02, device=device)
+        else:
+            auds = preproc.log_spectrogram(wave, [b[1] for b in batch], 111)
     ff = None
     if feats is not None:     # (b t) order: the windows' frame indices, reversed for the time-reversed windows
         idx = [j for b in batch for j in b[3]]
@@ -218,6 +244,8 @@ def inference_dataset(model, args):
             print("More frames are needed")
             continue
         snippet, batch = [], []
+        wave = _load_wav_16k(audio_path).reshape(-1).to(device) if os.path.exists(audio_path) else None   # once per video
+        n_wave = 0 if wave is None else wave.numel()
         img_size = (640, 480)
         loaded = {}
 
@@ -236,12 +264,11 @@ def inference_dataset(model, args):
                 if cache is not None:
                     cache.upto(i)
                 clip = torch.stack(snippet).permute(1, 0, 2, 3)          # [3,T,H,W]
-                aud = get_audio_feature(audio_path=audio_path, start_idx=first, fps=videos_fps[vname])
-                batch.append((clip, aud, os.path.basename(list_frames[i]), list(range(first, i + 1))))
+                st, ln = audio_segment(n_wave, first, videos_fps[vname]) if wave is not None else (0, 0)
+                batch.append((clip, (st, ln, 0), os.path.basename(list_frames[i]), list(range(first, i + 1)), wave))
                 if i < 2 * len_temporal - 2:      # first (len_temporal-1) frames: reversed clip + reversed audio
-                    aud_r = get_audio_feature(audio_path=audio_path, start_idx=first, fps=videos_fps[vname], mode=True)
-                    batch.append((torch.flip(clip, [1]), aud_r, os.path.basename(list_frames[first]),
-                                  list(range(i, first - 1, -1))))
+                    batch.append((torch.flip(clip, [1]), (st, ln, 1), os.path.basename(list_frames[first]),
+                                  list(range(i, first - 1, -1)), wave))
                 if len(batch) >= bs:
                     _flush(model, batch, vname, img_size, args, cache.feats if cache else None)
                     if cache is not None:

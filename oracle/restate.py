@@ -742,3 +742,33 @@ def saliency_metrics(pred, gt, fix=None):
         f = fix.reshape(B, -1).float()
         ns = (((s - s.mean(1, keepdim=True)) / (s.std(1, keepdim=True) + eps)) * f).sum(1) / f.sum(1)   # nss :93-107
     return torch.stack([kl, cc, sim, ns], 1)
+
+
+# ------------------------------------------------------------------------------- clip-loop pre-processing
+def frame_transform(rgb_u8, out_hw, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """inference.py:154-165 (torchvision Resize on a PIL image, ToTensor, Normalize): PIL itself does the resampling --
+    the reference's own dependency, so this function is pinned by construction."""
+    from PIL import Image
+    img = Image.fromarray(np.asarray(rgb_u8, dtype=np.uint8)).resize((out_hw[1], out_hw[0]), Image.BILINEAR)
+    t = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255.0)
+    return (t - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
+
+
+def log_spectrogram_window(wave, start, length, reverse=False, Wa=111):
+    """inference.py:41-58 on a 16 kHz mono wave [n]: Spectrogram(n_fft=512, hop_length=160) = torch.stft with a periodic
+    Hann window, centre + reflect padding, |.|^2 (what torchaudio.functional.spectrogram evaluates; torchaudio itself is
+    absent offline -> PARITY UNPINNED against torchaudio, pinned only against torch.stft), log(. + 1e-6), per-column
+    standardisation over the 257 bins (unbiased std), crop / pad with 0.02 to Wa columns.  length 0 = no audio."""
+    out = torch.zeros(1, 257, Wa) + 0.02
+    if length == 0:
+        return out
+    a = wave[start:start + length][None]
+    if reverse:
+        a = torch.flip(a, [1])
+    spec = torch.stft(a, n_fft=512, hop_length=160, win_length=512, window=torch.hann_window(512), center=True,
+                      pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+    a = torch.log(spec.abs().pow(2.0) + 1e-6)
+    a = (a - a.mean(dim=1, keepdim=True)) / (a.std(dim=1, keepdim=True) + 1e-6)
+    n = min(a.shape[-1], Wa)
+    out[:, :, :n] = a[:, :, :n]
+    return out

@@ -51,12 +51,80 @@ def test_blur_and_transform(tmp_path):
     ref = torch.nn.functional.conv2d(torch.nn.functional.conv2d(torch.nn.functional.pad(x[None, None], (5, 5, 5, 5), mode="reflect"),
                                                                 k.view(1, 1, 1, 11)), k.view(1, 1, 11, 1))[0, 0]
     assert np.abs(I.blur(x.numpy()) - ref.numpy()).max() < 1e-5
-    I._RESOLUTION[:] = [32, 48]
-    img, sz = I.torch_transform(os.path.join(str(tmp_path), "video_frames", "TOY", "clip1", "img_00001.jpg"))
-    assert tuple(img.shape) == (3, 32, 48) and sz == (64, 48) and -2.2 < img.min() < img.max() < 2.7
     assert I.normalize(np.array([1.0, 3.0])).tolist() == [0.0, 1.0]
     u8 = R.postprocess_u8(torch.randn(20, 30), (48, 64))
     assert u8.dtype == torch.uint8 and int(u8.min()) == 0 and int(u8.max()) == 255
+
+
+def test_preprocessing_oracle_and_tables(tmp_path):
+    """Host side of the GPU pre-processing: the fixed-point tap tables reproduce PIL's resize bit for bit (numpy emulation of
+    the two integer passes), the oracle's spectrogram window equals the reference-signature host function, and
+    audio_segment cuts what get_audio_feature cuts."""
+    from PIL import Image
+    from mspi_amd import inference as I
+    from mspi_amd.preproc import pil_bilinear_coeffs
+    from oracle import restate as R
+    rng = np.random.default_rng(0)
+    for Hin, Win, Hout, Wout in ((48, 64, 32, 48), (100, 150, 224, 384), (333, 517, 96, 160)):
+        img = rng.integers(0, 256, (Hin, Win, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((Wout, Hout), Image.BILINEAR))
+        hb, hk, _ = pil_bilinear_coeffs(Win, Wout)
+        vb, vk, _ = pil_bilinear_coeffs(Hin, Hout)
+        tmp = np.stack([np.clip(((img[:, x0:x0 + n].astype(np.int64) * hk[x, :n][None, :, None]).sum(1) + (1 << 21)) >> 22, 0, 255)
+                        for x, (x0, n) in enumerate(hb)], 1)
+        out = np.stack([np.clip(((tmp[y0:y0 + n] * vk[y, :n][:, None, None]).sum(0) + (1 << 21)) >> 22, 0, 255)
+                        for y, (y0, n) in enumerate(vb)], 0)
+        assert np.array_equal(out, ref)
+        t = R.frame_transform(img, (Hout, Wout))
+        assert tuple(t.shape) == (3, Hout, Wout) and -2.2 < t.min() < t.max() < 2.7
+    wav = _make_dataset(str(tmp_path))
+    wave = I._load_wav_16k(wav).reshape(-1)
+    for first, rev in ((3, False), (3, True), (20, False)):
+        st, ln = I.audio_segment(wave.numel(), first, "25")
+        a = R.log_spectrogram_window(wave, st, ln, rev)
+        assert torch.equal(a, I.get_audio_feature(wav, first, "25", mode=rev))
+    assert I.audio_segment(16000, 100, 25) == (0, 0)                   # window past the end of the wave: "no audio"
+    assert torch.equal(R.log_spectrogram_window(wave, 0, 0), torch.full((1, 257, 111), 0.02))
+
+
+@pytest.mark.gpu
+def test_gpu_preprocessing(dev, tmp_path):
+    """frame resize + normalise (bit-exact to PIL / torchvision's ops) and the batched log-spectrogram
+    kernel (vs the torch.stft oracle) on the GPU."""
+    from PIL import Image
+    from mspi_amd import inference as I
+    from mspi_amd import preproc as P
+    from mspi_amd._lib import MspiError
+    from oracle import restate as R
+    rng = np.random.default_rng(1)
+    for Hin, Win, Hout, Wout in ((480, 640, 224, 384), (48, 64, 32, 48), (100, 150, 224, 384), (224, 384, 224, 384)):
+        img = rng.integers(0, 256, (Hin, Win, 3), dtype=np.uint8)
+        got = P.resize_normalize(torch.from_numpy(img).to(dev), (Hout, Wout), I.IMAGENET_DEFAULT_MEAN, I.IMAGENET_DEFAULT_STD).cpu()
+        assert torch.equal(got, R.frame_transform(img, (Hout, Wout))), (Hin, Win, Hout, Wout)
+    _make_dataset(str(tmp_path))
+    I.device = dev
+    I._RESOLUTION[:] = [32, 48]
+    path = os.path.join(str(tmp_path), "video_frames", "TOY", "clip1", "img_00001.jpg")
+    t, sz = I.torch_transform(path)
+    assert t.is_cuda and sz == (64, 48)
+    assert torch.equal(t.cpu(), R.frame_transform(np.asarray(Image.open(path).convert("RGB")), (32, 48)))
+    # spectrogram windows: tone + noise, a chirp-free silent stretch, reversed windows, a short window (pads with 0.02)
+    g = torch.Generator().manual_seed(0)
+    n = 16000 * 3
+    tt = torch.arange(n) / 16000.0
+    wave = 0.3 * torch.sin(2 * math.pi * 440 * tt) + 0.05 * torch.randn(n, generator=g)
+    wave[20000:24000] *= 1e-3
+    segs = [(0, 21120, 0), (1234, 21120, 1), (16000, 21121, 0), (30000, 5000, 0), (40000, 8000, 1), (0, 0, 0), (47000, 300, 0)]
+    out = P.log_spectrogram(wave.to(dev), segs, 111).cpu()
+    assert tuple(out.shape) == (len(segs), 1, 257, 111)
+    for b, (st, ln, rev) in enumerate(segs):
+        ref = R.log_spectrogram_window(wave, st, ln, bool(rev))
+        err = (out[b] - ref).abs().max().item()
+        assert err < 2e-3, "window %d: max abs err %.3e" % (b, err)      # fp32 FFT (oracle) vs fp64-accumulated DFT
+    with pytest.raises(MspiError, match="outside"):
+        P.log_spectrogram(wave.to(dev), [(n - 100, 300, 0)])
+    with pytest.raises(MspiError, match="reflect"):
+        P.log_spectrogram(wave.to(dev), [(0, 200, 0)])
 
 
 @pytest.mark.gpu
@@ -97,7 +165,7 @@ def test_clip_loop_end_to_end(dev, tmp_path):
     assert len(outs) == 34 and outs[0] == "img_00001.jpg"
     # frame 20 (window frames 5..20) against the oracle pipeline
     frames = [I.torch_transform(os.path.join(root, "video_frames", "TOY", "clip1", "img_%05d.jpg" % (i + 1)))[0] for i in range(4, 20)]
-    clip = torch.stack(frames).permute(1, 0, 2, 3)[None]
+    clip = torch.stack(frames).permute(1, 0, 2, 3)[None].cpu()
     aud = I.get_audio_feature(os.path.join(root, "video_audio", "TOY", "clip1", "clip1.wav"), 4, "25")[None]
     cfg = model.cfg
     with torch.no_grad():
