@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--wa", type=int, default=300, help="spectrogram columns (BASELINE: 300; reference default 111)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--inflight", type=int, default=2, help="hipGraphs of the forward kept in flight: consecutive steps (batches) "
+                    "replay round-robin on this many streams, so the low-occupancy tail of one batch overlaps the head of the "
+                    "next (each step is still one full forward of one batch; 1 = strictly one batch at a time)")
     ap.add_argument("--no-autotune", action="store_true", help="keep the library's tile heuristic (default: time the "
                     "kernel instantiations per conv shape during the first, untimed forward -- cudnn.benchmark's role upstream)")
     ap.add_argument("--tune-cache", default=None, help="JSON file of tile choices: loaded when it exists (no tuning launches, "
@@ -140,30 +143,51 @@ def main():
     if args.tune_cache and not have_cache and rank == 0:
         E.save_autotune(args.tune_cache)
     torch.cuda.synchronize()
-    graph = None
+    graphs, outs, streams = [], [out], []
     if not args.no_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            model(clips, audio)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        # thread_local: the capture must not trip over CUDA calls of other threads (the RCCL watchdog polls events)
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            out, loss = model(clips, audio)
+        outs = []
+        for _ in range(max(1, args.inflight)):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model(clips, audio)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            # thread_local: the capture must not trip over CUDA calls of other threads (the RCCL watchdog polls events)
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                o, loss = model(clips, audio)
+            graphs.append(g)
+            outs.append(o)
+            streams.append(side)
+    depth = max(1, len(graphs))
+    done = [torch.cuda.Event() for _ in range(depth)]
+    collected = [None] * depth                    # event after the last gather that read outs[k]
+    counter = [0]
 
     def step():
-        if graph is not None:
-            graph.replay()
-            o = out
+        k = counter[0] % depth
+        counter[0] += 1
+        if graphs:
+            if collected[k] is not None:          # the previous replay's maps must have left outs[k]
+                streams[k].wait_event(collected[k])
+            with torch.cuda.stream(streams[k]):
+                graphs[k].replay()
+                done[k].record()
+            o = outs[k]
+            if world > 1:
+                torch.cuda.current_stream().wait_event(done[k])
         else:
             o, _ = model(clips, audio)
+            outs[0] = o
         if world > 1:                             # map collection over xGMI
             if args.backend == "nccl":
                 dist.gather(o, gathered, dst=0)
             else:                                 # gloo has no device gather: rehearsal only
                 dist.gather(o.cpu(), [g.cpu() for g in gathered] if gathered is not None else None, dst=0)
+            if graphs:
+                collected[k] = torch.cuda.Event()
+                collected[k].record()
         return o
 
     for _ in range(args.warmup):
@@ -184,7 +208,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    ok = bool(torch.isfinite(out).all().item()) and abs(torch.logsumexp(out.flatten(1), 1)).max().item() < 1e-3
+    ok = all(bool(torch.isfinite(o).all().item()) and abs(torch.logsumexp(o.flatten(1), 1)).max().item() < 1e-3 for o in outs)
+    if depth > 1:                                 # every graph in flight computed the same maps
+        ok = ok and all(torch.equal(outs[0], o) for o in outs[1:])
     if not ok:
         raise SystemExit("bench: the saliency maps are not finite log-probability maps")
 
@@ -203,10 +229,22 @@ def main():
         "config": {"workload": "%s motion encoder + ConvNeXt-T + ResNet18 audio + SyncBlock + decoder (AudioVisualSaliencyModel "
                                "forward), batch %d/GPU, clips 3x16x%dx%d, spectrogram 1x257x%d, inputs resident in HBM"
                                % (name, B, S, S, args.wa),
-                   "global_batch": world * B, "launch": "eager" if graph is None else "hipGraph replay",
+                   "global_batch": world * B,
+                   "launch": "eager" if not graphs else "hipGraph replay, %d batch%s in flight" % (depth, "es" if depth > 1 else ""),
                    "parallelism": "clip-sharded x%d (weights broadcast once, maps gathered per step over RCCL)" % world
                    if world > 1 else "single GPU"},
     }
+
+    if graphs:       # latency of ONE batch alone on the chip (no neighbouring batch in flight): median of 7 replays
+        lat = []
+        for _ in range(7):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            with torch.cuda.stream(streams[0]):
+                graphs[0].replay()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+        line["latency_ms_per_batch"] = round(1e3 * sorted(lat)[len(lat) // 2], 4)
 
     if not args.no_roofline:
         # per-launch HIP-event timing of every C-ABI call: eager, same inputs, ONE stream (the branch overlap is
