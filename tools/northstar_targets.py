@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""The two kernel-level targets BASELINE.json's north_star names, measured on the box:
+  (1) X3D-L conv path at batch 8 as a fraction of the HBM roofline: backbone-only forward (hipGraph replay, HIP-event
+      timing over `reps` replays) against SURVEY 8d's 1.33 GB of algorithmic traffic per clip;
+  (2) MViTv2-S attention at batch 8 as a fraction of the dense f16 MFMA peak: per-launch HIP events of every attention
+      launch (E.Profiler) against 4*B*H*Nq*Nk*D algorithmic flops; an f16x3 kernel issues 3 MFMA flops per algorithmic one.
+Prints one JSON object.  python tools/northstar_targets.py > profiles/rNN_northstar.json"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mspi_amd import engine as E, testing as T
+from mspi_amd.config import cfg
+
+dev = torch.device("cuda")
+B, reps = 8, 30
+HBM_PEAK, F16_PEAK = 8000.0, 2500.0
+out = {}
+so, sys.stdout = sys.stdout, open(os.devnull, "w")
+clips, _ = T.synth_inputs(B, 16, 224, 224, seed=100, device=dev)
+
+
+def replay_ms(fn):
+    E.autotune(True)
+    fn()
+    E.autotune(False)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        fn()
+    for _ in range(3):
+        g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+# (1) X3D-L backbone alone
+from mspi_amd.backbones.X3D import X3D
+x3d = T.seeded(lambda: X3D(cfg.MODEL.X3D.PATH_CFG), 0).to(dev)
+ms = replay_ms(lambda: x3d.forward_cl([clips]))
+gbs = B * 1.33e9 / (ms * 1e-3) / 1e9
+out["x3d_conv_path_batch8"] = {"ms_per_batch": round(ms, 3), "clips_per_s": round(B / ms * 1e3, 1), "algorithmic_GB_per_clip": 1.33,
+                               "achieved_GBs": round(gbs, 1), "hbm_peak_GBs": HBM_PEAK, "frac_of_hbm_peak": round(gbs / HBM_PEAK, 4),
+                               "target": 0.60, "dtype": "fp32 activations"}
+
+# (2) MViTv2-S attention
+from mspi_amd.backbones.MViT import MViT
+mv = T.seeded(lambda: MViT(cfg.MODEL.MVIT2.PATH_CFG), 0).to(dev)
+E.autotune(True)
+mv.forward_cl([clips])
+E.autotune(False)
+torch.cuda.synchronize()
+with E.Profiler() as prof:
+    for _ in range(3):
+        mv.forward_cl([clips])
+torch.cuda.synchronize()
+summ = prof.summary()
+tot = sum(d["ms"] for d in summ.values())
+a = summ["attention"]
+tf = a["flops"] / a["ms"] / 1e9
+out["mvitv2s_attention_batch8"] = {"launches_per_forward": a["calls"] // 3, "ms_per_forward": round(a["ms"] / 3, 3),
+                                   "share_of_backbone": round(a["ms"] / tot, 4), "algorithmic_TFLOPs": round(tf, 1),
+                                   "mfma_issued_TFLOPs": round(3 * tf, 1), "f16_mfma_peak_TFLOPs": F16_PEAK,
+                                   "frac_of_mfma_peak_algorithmic": round(tf / F16_PEAK, 4),
+                                   "mfma_pipe_frac": round(3 * tf / F16_PEAK, 4), "target": 0.40,
+                                   "dtype": "f16x3 split products (fp32-accurate), fp32 accumulate"}
+per = {}
+for name, fl, by, e0, e1, det in prof.records:
+    if name == "attention":
+        d = per.setdefault(det, [0, 0.0, fl])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1)
+out["mvitv2s_attention_batch8"]["per_shape"] = [
+    {"shape": k, "launches": v[0] // 3, "us": round(1e3 * v[1] / v[0], 1), "algorithmic_TFLOPs": round(v[2] / (v[1] / v[0]) / 1e9, 1)}
+    for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])]
+sys.stdout = so
+print(json.dumps(out, indent=1))
