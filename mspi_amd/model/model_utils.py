@@ -263,12 +263,17 @@ class ConvNextBlock(HipModule):
                 "ds": E.pack_dwconv(self.dwconv_s.weight, self.dwconv_s.bias, None, (1, 1, 1), (0, 3, 3)),
                 "ln": (_f(self.norm.norm.weight), _f(self.norm.norm.bias)),
                 "p1": E.pack_conv(self.pwconv1.weight, self.pwconv1.bias, act=E.ACT_GELU),
-                "p2": E.pack_conv(self.pwconv2.weight, self.pwconv2.bias)}
+                "p2": E.pack_conv(self.pwconv2.weight, self.pwconv2.bias),
+                # LN -> 1x1x1 -> GELU -> 1x1x1 -> +x in one launch where the fused kernel covers the width (dim 192)
+                "fused": E.pack_mlp(self.pwconv1.weight.flatten(1), self.pwconv1.bias, self.pwconv2.weight.flatten(1),
+                                    self.pwconv2.bias) if E.mlp_supported(self.pwconv1.in_channels, self.pwconv1.out_channels) else None}
 
     def run(self, x, out=None):
         pk = self.pk
-        y = E.layernorm(E.dwconv(E.dwconv(x, pk["dt"]), pk["ds"]), *pk["ln"], 1e-5)
-        return E.conv(E.conv(y, pk["p1"]), pk["p2"], res=x, out=out)
+        y = E.dwconv(E.dwconv(x, pk["dt"]), pk["ds"])
+        if pk["fused"] is not None and y.M >= 4096:      # below that the two tiled GEMMs (split-K on the small maps) win
+            return E.mlp(y, pk["fused"], res=x, ln=pk["ln"], eps=1e-5, out=out)
+        return E.conv(E.conv(E.layernorm(y, *pk["ln"], 1e-5), pk["p1"]), pk["p2"], res=x, out=out)
 
 
 class StaticSaliencyModelConvNext(HipModule):

@@ -13,7 +13,7 @@ echo "bench done"; cat $OUT/bench.json
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o r --output-format csv -- python3 bench.py --steps 20 --warmup 5 --tune-cache $CACHE --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 echo "trace done"
 export MSPI_STREAMS=0
-rocprofv3 --kernel-trace --stats -d $OUT/trace_serial -o r --output-format csv -- python3 bench.py --steps 20 --warmup 5 --tune-cache $CACHE --no-cpu-baseline > $OUT/bench_under_rocprof_serial.json 2> $OUT/trace_serial.err
+rocprofv3 --kernel-trace --stats -d $OUT/trace_serial -o r --output-format csv -- python3 bench.py --steps 20 --warmup 5 --inflight 1 --tune-cache $CACHE --no-cpu-baseline > $OUT/bench_under_rocprof_serial.json 2> $OUT/trace_serial.err
 echo "serial trace done"
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o r --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-graph --tune-cache $CACHE --no-cpu-baseline --no-roofline > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 echo "fetch done"
