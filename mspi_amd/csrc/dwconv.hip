@@ -293,6 +293,176 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const DwArgs p, int CG, in
   }
 }
 
+
+// LDS-staged kernel (stride 1, square K x K spatial kernels, any temporal extent): a block owns TT output frames x a
+// TH x TW spatial tile x CG channel-vec4s.  Why: the strip / tile kernels above fetch every input 13-17 times through
+// L1 (they run at the texture-address rate, 1.4-2.4 TB/s algorithmic) in kT dependent load phases.  Here
+//   * the block's input region ((TT+kT-1) x (TH+K-1) x (TW+K-1) pixels x CG vec4, zero-filled outside the map) is brought
+//     into LDS ONCE by a single batch of independent, coalesced 16-B loads (one latency phase): (1 + (kT-1)/TT) x halo
+//     = 2-2.5 L1 requests per output instead of 13.5-17.5;
+//   * outputs are then computed from LDS with the same register sliding window along W (SW outputs per thread and
+//     row), weights from LDS as in the tile kernel, no bounds checks in the inner loops.
+// grid = (tt x th x tw tiles [XCD-remapped], channel groups, N); thread -> (channel-vec4 = tid % CG, strip = tid / CG).
+// POOL partial rows: pool[n][tile][C], each channel group fills its own slice, fixed summation order.
+__device__ __forceinline__ int fdiv(int a, float inv_b) { return __float2int_rz(((float)a + 0.5f) * inv_b); }
+
+template <int K, int SW, bool POOL>
+__global__ __launch_bounds__(256) void dw_lds_kernel(const DwArgs p, int CG, int TT, int TH, int nsw, int nTh, int nTw,
+                                                     float inv_cg, float inv_rw, float inv_rh) {
+  extern __shared__ float4 dwl[];
+  const int kT = p.kT;
+  const int TWp = nsw * SW;
+  const int RT = TT + kT - 1, RH = TH + K - 1, RW = TWp + K - 1;
+  const int taps = kT * K * K;
+  float4* xin = dwl;                              // [RT][RH][RW][CG]
+  float4* wl = dwl + RT * RH * RW * CG;           // [taps][CG]
+  float4* stage = wl + taps * CG;                 // POOL: [256]
+  const int tid = threadIdx.x;
+  const int n = blockIdx.z, g = blockIdx.y;
+  const int nblk = gridDim.x;
+  const int lb = xcd_remap(blockIdx.x, nblk);
+  const int tw = lb % nTw, th = (lb / nTw) % nTh, tt = lb / (nTw * nTh);
+  const int to0 = tt * TT, ho0 = th * TH, wo0 = tw * TWp;
+  const int t0 = to0 - p.padT, h0 = ho0 - p.padH, w0 = wo0 - p.padW;
+  for (int i = tid; i < taps * CG; i += 256) {
+    const int tap = fdiv(i, inv_cg), c = i - tap * CG;
+    wl[i] = *reinterpret_cast<const float4*>(p.w + (long)tap * p.C + (g * CG + c) * 4);
+  }
+  const float* xb = p.x + ((long)n * p.T * p.H * p.W) * p.ldx + g * CG * 4;
+  const int E = RT * RH * RW * CG;
+  constexpr int U = 8;
+  for (int base = tid; base < E; base += 256 * U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = base + u * 256;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < E) {
+        const int px = fdiv(e, inv_cg), c = e - px * CG;
+        const int q = fdiv(px, inv_rw), rw = px - q * RW;
+        const int dt = fdiv(q, inv_rh), rh = q - dt * RH;
+        const int t = t0 + dt, h = h0 + rh, w = w0 + rw;
+        if ((unsigned)t < (unsigned)p.T && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W)
+          v[u] = *reinterpret_cast<const float4*>(xb + (((long)t * p.H + h) * p.W + w) * p.ldx + c * 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = base + u * 256;
+      if (e < E) xin[e] = v[u];
+    }
+  }
+  __syncthreads();
+  const int tpc = 256 / CG;                       // strips in flight per pass
+  const int cvl = tid % CG, sp = tid / CG;
+  const int cv = g * CG + cvl;
+  const int strips = TT * TH * nsw;
+  float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (sp < tpc) {
+    const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + cv * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = sp; s < strips; s += tpc) {
+      const int cs = s % nsw, r = (s / nsw) % TH, ot = s / (nsw * TH);
+      const int to = to0 + ot, ho = ho0 + r, wo = wo0 + cs * SW;
+      if (to >= p.To || ho >= p.Ho || wo >= p.Wo) continue;
+      float4 acc[SW];
+#pragma unroll
+      for (int o = 0; o < SW; ++o) acc[o] = bv;
+      for (int dt = 0; dt < kT; ++dt) {
+        if ((unsigned)(to - p.padT + dt) >= (unsigned)p.T) continue;      // that frame of the region is all zeros
+        const float4* wt = wl + (dt * K * K) * CG + cvl;
+#pragma unroll
+        for (int dh = 0; dh < K; ++dh) {
+          const float4* row = xin + ((((ot + dt) * RH + r + dh) * RW) + cs * SW) * CG + cvl;
+          float4 x[SW + K - 1];
+#pragma unroll
+          for (int j = 0; j < SW + K - 1; ++j) x[j] = row[j * CG];
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const float4 wv = wt[(dh * K + k) * CG];
+#pragma unroll
+            for (int o = 0; o < SW; ++o) {
+              acc[o].x = fmaf(x[o + k].x, wv.x, acc[o].x);
+              acc[o].y = fmaf(x[o + k].y, wv.y, acc[o].y);
+              acc[o].z = fmaf(x[o + k].z, wv.z, acc[o].z);
+              acc[o].w = fmaf(x[o + k].w, wv.w, acc[o].w);
+            }
+          }
+        }
+      }
+      const long orow = (((long)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
+#pragma unroll
+      for (int o = 0; o < SW; ++o) {
+        if (wo + o < p.Wo) {
+          float4 v = acc[o];
+          if (POOL) { psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w; }
+          v.x = act_apply(v.x, p.act); v.y = act_apply(v.y, p.act); v.z = act_apply(v.z, p.act); v.w = act_apply(v.w, p.act);
+          *reinterpret_cast<float4*>(p.y + (orow + o) * p.ldy + cv * 4) = v;
+        }
+      }
+    }
+  }
+  if (POOL) {
+    stage[tid] = psum;
+    __syncthreads();
+    if (tid < CG) {   // fixed order over the block's strips: bitwise reproducible
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < tpc; ++q) { const float4 v = stage[q * CG + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+      *reinterpret_cast<float4*>(p.pool + ((long)n * nblk + lb) * p.C + (g * CG + tid) * 4) = t;
+    }
+  }
+}
+
+struct LdsCfg { int K, SW, CG, G, TT, TH, nsw, nTt, nTh, nTw; long nblk; size_t lds; };
+
+// Geometry of the LDS-staged kernel for this descriptor; false = not covered (strided, non-square, ...).
+static bool lds_cfg(const MspiDwConvDesc* d, LdsCfg& c) {
+  static const bool off = getenv("MSPI_DW_LDS") != nullptr && getenv("MSPI_DW_LDS")[0] == '0';   // A/B switch
+  if (off || d->kH != d->kW || !(d->kW == 3 || d->kW == 5 || d->kW == 7)) return false;
+  if (d->strT != 1 || d->strH != 1 || d->strW != 1 || d->kT > 7) return false;
+  // Measured (tools/dw_probe.py, batch 8): staging wins where a thread of the strip kernel would re-fetch the most --
+  // 5x5x5 (135 -> 110 us at 8x56^2x64) and 7x7 on maps of 14 or less (48.8 -> 40.7 us at 128x14^2x384) -- and loses on every
+  // 3x3x3 shape (27.7 -> 33-47 us at 8x16x14^2x216: the halo of a 3-frame window costs more than L1 re-reads) and on the
+  // wide 7x7 maps, where the register-tile kernel already loads each row once.  MSPI_DW_LDS=1 forces it everywhere.
+  static const bool all = getenv("MSPI_DW_LDS") != nullptr && getenv("MSPI_DW_LDS")[0] == '1';
+  if (!all && !(d->kW == 5 || (d->kW == 7 && d->W <= 14 && d->W > 7))) return false;
+  const int To = d->T + 2 * d->padT - d->kT + 1, Ho = d->H + 2 * d->padH - d->kH + 1, Wo = d->W + 2 * d->padW - d->kW + 1;
+  if (To <= 0 || Ho <= 0 || Wo <= 0) return false;
+  const int CV = d->C / 4;
+  c.K = d->kW;
+  c.SW = (Wo % 7 == 0) ? 7 : 4;
+  const int taps = d->kT * c.K * c.K;
+  static const long budget = getenv("MSPI_DW_LDS_KB") ? atol(getenv("MSPI_DW_LDS_KB")) * 1024 : 48 * 1024;
+  // exhaustive search over (channel group, frames, rows, strips per row): least staged input per output (the halo factor),
+  // subject to the LDS budget and to at least two blocks per CU
+  bool found = false;
+  double best = 1e30;
+  const int nsw_max = (Wo + c.SW - 1) / c.SW;
+  for (int cg = 1; cg <= 8; ++cg) {
+    if (CV % cg) continue;
+    for (int TT = 1; TT <= (d->kT == 1 ? 1 : 8) && TT <= To; ++TT)
+      for (int TH = 1; TH <= Ho && TH <= 28; ++TH)
+        for (int nsw = 1; nsw <= nsw_max && nsw <= 8; ++nsw) {
+          const int TWp = nsw * c.SW;
+          const long lds = ((long)(TT + d->kT - 1) * (TH + c.K - 1) * (TWp + c.K - 1) * cg + (long)taps * cg + 256) * 16;
+          if (lds > budget) continue;
+          const long nTt = (To + TT - 1) / TT, nTh = (Ho + TH - 1) / TH, nTw = (Wo + TWp - 1) / TWp;
+          const long blocks = nTt * nTh * nTw * (CV / cg) * d->N;
+          // staged elements per useful output (tiles that overhang the map count as waste too)
+          double rho = (double)(nTt * (TT + d->kT - 1)) * (nTh * (TH + c.K - 1)) * (nTw * (TWp + c.K - 1)) / ((double)To * Ho * Wo);
+          if (blocks < 512) rho *= 4.0;                   // starving the chip is worse than any halo
+          rho *= 1.0 + 0.25 / cg;                         // prefer wide channel groups (longer contiguous runs per pixel)
+          const long strips = (long)TT * TH * nsw;
+          if (strips * cg < 192) rho *= 2.0;              // most of the block's threads must have a strip
+          if (rho < best) {
+            best = rho; found = true;
+            c.CG = cg; c.G = CV / cg; c.TT = TT; c.TH = TH; c.nsw = nsw; c.lds = (size_t)lds;
+            c.nTt = (int)nTt; c.nTh = (int)nTh; c.nTw = (int)nTw; c.nblk = nTt * nTh * nTw;
+          }
+        }
+  }
+  return found && c.nblk < (1L << 31) && c.G < 65536 && d->N < 65536;
+}
+
 struct TileCfg { int K, STR, SW, SH, CG, G, PB, HS, S; long nblk; };
 
 // The tile kernel covers square (k, K, K) kernels, K in {3, 7}, equal H/W stride 1 (or 2 for K = 3).
@@ -369,7 +539,21 @@ extern "C" int mspi_dwconv_fwd(const MspiDwConvDesc* d, const float* x, const fl
   const int strip = strip_variant(d);
   MSPI_REQUIRE(!pool || strip >= 0, "mspi_dwconv_fwd: SE pooling needs a (k,3,3)/(k,5,5)/(k,7,7) kernel with W-stride 1 or 2");
   TileCfg tc;
-  if (tile_cfg(d, tc)) {
+  LdsCfg lc;
+  if (lds_cfg(d, lc)) {
+    const dim3 grid((unsigned)lc.nblk, (unsigned)lc.G, (unsigned)a.N);
+    const int RW = lc.nsw * lc.SW + lc.K - 1, RH = lc.TH + lc.K - 1;
+    const float icg = 1.f / (float)lc.CG, irw = 1.f / (float)RW, irh = 1.f / (float)RH;
+#define MSPI_DWL(KK, SWW)                                                                                              \
+    do {                                                                                                               \
+      if (pool) hipLaunchKernelGGL((dw_lds_kernel<KK, SWW, true>), grid, dim3(256), lc.lds, s, a, lc.CG, lc.TT, lc.TH, lc.nsw, lc.nTh, lc.nTw, icg, irw, irh);  \
+      else hipLaunchKernelGGL((dw_lds_kernel<KK, SWW, false>), grid, dim3(256), lc.lds, s, a, lc.CG, lc.TT, lc.TH, lc.nsw, lc.nTh, lc.nTw, icg, irw, irh);      \
+    } while (0)
+    if (lc.K == 3) { if (lc.SW == 7) MSPI_DWL(3, 7); else MSPI_DWL(3, 4); }
+    else if (lc.K == 5) { if (lc.SW == 7) MSPI_DWL(5, 7); else MSPI_DWL(5, 4); }
+    else { if (lc.SW == 7) MSPI_DWL(7, 7); else MSPI_DWL(7, 4); }
+#undef MSPI_DWL
+  } else if (tile_cfg(d, tc)) {
     const dim3 grid((unsigned)tc.nblk, (unsigned)tc.G, (unsigned)a.N);
     const size_t lds = ((size_t)a.kT * tc.K * tc.K * tc.CG + (pool ? 256 : 0)) * sizeof(float4);
 #define MSPI_DWT(KK, ST, SWW)                                                                                            \
@@ -406,6 +590,8 @@ extern "C" int mspi_dwconv_fwd(const MspiDwConvDesc* d, const float* x, const fl
 
 extern "C" int mspi_dwconv_pool_rows(const MspiDwConvDesc* d) {
   if (!d || strip_variant(d) < 0) return -1;
+  LdsCfg lc;
+  if (lds_cfg(d, lc)) return (int)lc.nblk;
   TileCfg tc;
   if (tile_cfg(d, tc)) return (int)tc.nblk;
   const long Wo = (d->W + 2 * d->padW - d->kW) / d->strW + 1;
