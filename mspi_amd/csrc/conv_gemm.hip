@@ -383,6 +383,7 @@ using namespace mspi;
 namespace mspi {
 int launch_conv_ad(ConvArgs& a, long Ml, int force_bn, int* cfg, hipStream_t s);
 int launch_conv_ad8(ConvArgs& a, long Ml, int bn, int* cfg, hipStream_t s);
+int launch_conv_sp(ConvArgs& a, long Ml, int bn, int rows, int* cfg, hipStream_t s);
 }
 
 static thread_local int g_last_cfg = 0;
@@ -452,6 +453,7 @@ static int conv_fwd_impl(const MspiConvDesc* d, const float* x, const float* w, 
   static const int dbg = getenv("MSPI_CONV_DBG") ? atoi(getenv("MSPI_CONV_DBG")) : 0;
   a.dbg = dbg;
   a.ws = ws; a.ksplit = ksplit;
+  a.xs = nullptr; a.ldxs = 0; a.xplane = 0; a.ys = nullptr; a.ldys = 0; a.yplane = 0;
   if (ws) {
     // split-K (mspi_conv_splitk_fwd): 64x64 tiles, gridDim.y = ksplit slices of the K loop, then the ordered reduction
     MSPI_REQUIRE(!gate && (d->Cout & 3) == 0 && (d->ldy & 3) == 0 && (!res || (d->ldr & 3) == 0) && aligned16(y) && aligned16(ws) &&
@@ -551,4 +553,82 @@ extern "C" int mspi_conv_splitk_fwd(const MspiConvDesc* d, const float* x, const
                                     const float* res, float* y, void* workspace, int32_t ksplit, mspi_stream_t stream) {
   MSPI_REQUIRE(workspace, "mspi_conv_splitk_fwd: null workspace");
   return conv_fwd_impl(d, x, w, bias, res, nullptr, y, (float*)workspace, ksplit, stream);
+}
+
+
+// ---- pre-split activations -------------------------------------------------------------------------------------------
+namespace mspi {
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long ldx, _Float16* __restrict__ out,
+                                                          long ldo, long plane, long M, int K4) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * K4) return;
+  const long m = idx / K4;
+  const int c = (int)(idx - m * K4) * 4;
+  const float4 v = *reinterpret_cast<const float4*>(x + m * ldx + c);
+  const float a[4] = {v.x, v.y, v.z, v.w};
+  v4h h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { _Float16 hh, ll; split_f16(a[e], hh, ll); h[e] = hh; l[e] = ll; }
+  *reinterpret_cast<v4h*>(out + m * ldo + c) = h;
+  *reinterpret_cast<v4h*>(out + plane + m * ldo + c) = l;
+}
+}  // namespace mspi
+
+extern "C" int mspi_split_planes_fwd(const float* x, int64_t ldx, int64_t M, int32_t K, void* planes, int64_t ldo, int64_t plane,
+                                     mspi_stream_t stream) {
+  MSPI_REQUIRE(x && planes && M > 0 && K > 0 && (K & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0 && ldo >= K && plane >= M * ldo &&
+                   aligned16(x) && aligned16(planes) && (plane & 7) == 0,
+               "mspi_split_planes_fwd: K / ldx / ldo multiples of 4, 16-B aligned pointers, plane >= M*ldo");
+  const long total = M * (K / 4);
+  MSPI_REQUIRE((total + 255) / 256 < (1L << 31), "mspi_split_planes_fwd: grid too large");
+  hipLaunchKernelGGL(mspi::split_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long)ldx, (_Float16*)planes, (long)ldo, (long)plane, (long)M, K / 4);
+  return check_launch("mspi_split_planes_fwd");
+}
+
+extern "C" int mspi_gemm_sp_fwd(const MspiConvDesc* d, const void* x_planes, int64_t ldx, int64_t xplane, const float* w,
+                                const float* bias, const float* res, float* y, void* y_planes, int64_t ldys, int64_t yplane,
+                                mspi_stream_t stream) {
+  MSPI_REQUIRE(d && x_planes && w && (y || y_planes), "mspi_gemm_sp_fwd: null argument");
+  MSPI_REQUIRE(d->kT == 1 && d->kH == 1 && d->kW == 1 && d->strT == 1 && d->strH == 1 && d->strW == 1 && d->padT == 0 &&
+                   d->padH == 0 && d->padW == 0, "mspi_gemm_sp_fwd: a plain GEMM on rows (1x1x1, stride 1, no padding)");
+  MSPI_REQUIRE(d->prec == PREC_F16X3 && d->w_scale > 0.f && d->C > 0 && (d->C % BK) == 0 && d->ldw == d->C,
+               "mspi_gemm_sp_fwd: f16x3 weights, K a multiple of 32 with ldw == K");
+  MSPI_REQUIRE((ldx & 7) == 0 && ldx >= d->C && (xplane & 7) == 0 && aligned16(x_planes) && aligned16(w),
+               "mspi_gemm_sp_fwd: plane rows must be 16-B aligned");
+  const long Ml = (long)d->N * d->T * d->H * d->W;
+  MSPI_REQUIRE(Ml > 0 && Ml < (1L << 31) && xplane >= Ml * ldx, "mspi_gemm_sp_fwd: bad extent");
+  MSPI_REQUIRE(!y_planes || (ldys >= d->Cout && yplane >= Ml * ldys && (d->Cout % 32) == 0 && (ldys & 1) == 0 && (yplane & 1) == 0 &&
+                              aligned16(y_planes)), "mspi_gemm_sp_fwd: output planes need Cout %% 32 == 0 and even strides");
+  MSPI_REQUIRE(!y || d->ldy >= d->Cout, "mspi_gemm_sp_fwd: ldy < Cout");
+  MSPI_REQUIRE(!res || d->ldr >= d->Cout, "mspi_gemm_sp_fwd: ldr < Cout");
+  ConvArgs a;
+  a.x = nullptr; a.w = w; a.bias = bias; a.res = res; a.gate = nullptr; a.y = y;
+  a.N = d->N; a.T = d->T; a.H = d->H; a.W = d->W; a.C = d->C;
+  a.sN = a.sT = a.sH = a.sW = 0; a.sC = 1;
+  a.kT = a.kH = a.kW = 1; a.strT = a.strH = a.strW = 1; a.padT = a.padH = a.padW = 0;
+  a.To = d->T; a.Ho = d->H; a.Wo = d->W; a.Cout = d->Cout;
+  a.ldy = d->ldy; a.ldw = d->ldw; a.ldr = d->ldr; a.act = d->act;
+  a.M = (int)Ml; a.K = d->C; a.rows_per_sample = d->T * d->H * d->W;
+  a.out_scale = 1.0f / d->w_scale;
+  a.dbg = 0; a.ws = nullptr; a.ksplit = 1;
+  a.xs = (const _Float16*)x_planes; a.ldxs = ldx; a.xplane = xplane;
+  a.ys = (_Float16*)y_planes; a.ldys = ldys; a.yplane = yplane;
+  int bn, rows = 128;
+  switch (d->tile) {
+    case 6: bn = 128; break;
+    case 7: bn = 64; break;
+    case 9: bn = 96; break;
+    case 10: bn = 192; break;
+    case 11: bn = 256; break;
+    case 12: bn = 256; rows = 256; break;
+    case 13: bn = 192; rows = 256; break;
+    case 14: bn = 128; rows = 256; break;
+    default: bn = d->Cout <= 64 ? 64 : (d->Cout % 192 == 0 ? 192 : 128); break;
+  }
+  int cfg = 0;
+  const int rc = launch_conv_sp(a, Ml, bn, rows, &cfg, (hipStream_t)stream);
+  MSPI_REQUIRE(rc == 0, "mspi_gemm_sp_fwd: tile %d could not be launched", d->tile);
+  g_last_cfg = cfg;
+  return check_launch("mspi_gemm_sp_fwd");
 }

@@ -26,8 +26,9 @@ typedef __attribute__((address_space(3))) void lds_void;
 // NW: waves per workgroup = 32-row slabs of the tile (4: 128 x BN, two workgroups per CU; 8: 256 x BN, one workgroup per
 // CU whose eight waves share ONE weight tile -- 1.67x fewer staged bytes per MFMA and a 1.33x longer compute phase to
 // cover the latency of the next stage's DMA)
-template <int BN, bool GATE, bool DENSE, int NW>
+template <int BN, bool GATE, bool DENSE, int NW, bool APRE = false>
 __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArgs p) {
+  static_assert(!APRE || (DENSE && !GATE), "pre-split activations: plain GEMM on rows only");
   constexpr int BM = 32 * NW;
   constexpr int TN = BN / 32;
   constexpr int A_BYTES = BM * 32 * 4;          // raw fp32 activations: 128 rows x 32 k
@@ -84,7 +85,21 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
 
   auto issue_stage = [&](int st, int k0) {
     unsigned char* base = smem + st * STAGE;
-    if (DENSE) {
+    if (APRE) {
+      // the A tile as two f16 planes of BM rows x 64 B, staged exactly like a weight plane: group q = 16 rows,
+      // row r = 16 q + lane/4, slot lane%4 holds segment slot ^ ((r>>2)&3)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = i * NW + wave;
+        const int m = m0 + q * 16 + (lane >> 2);
+        const bool ok = m < p.M;
+        const _Float16* src = p.xs + (long)(ok ? m : 0) * p.ldxs + k0 + b_seg * 8;
+        const void* s_hi = ok ? (const void*)src : (const void*)g_zero16;
+        const void* s_lo = ok ? (const void*)(src + p.xplane) : (const void*)g_zero16;
+        __builtin_amdgcn_global_load_lds(s_hi, (lds_void*)(base + q * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(s_lo, (lds_void*)(base + A_BYTES / 2 + q * 1024), 16, 0, 0);
+      }
+    } else if (DENSE) {
       const int kk = k0 + a_chunk * 4;
       const bool kin = kk < p.C;
 #pragma unroll
@@ -148,10 +163,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
   };
   auto frag_read = [&](Frag& f, int st, int sub, int k0) {
     const unsigned char* base = smem + st * STAGE;
-    const float* As = reinterpret_cast<const float*>(base);
-    const int c0 = 4 * lh + 2 * sub;   // 16-B chunk index of this lane's first 4 floats
-    f.v0 = *reinterpret_cast<const float4*>(&As[frow * 32 + ((c0 ^ fsw) << 2)]);
-    f.v1 = *reinterpret_cast<const float4*>(&As[frow * 32 + (((c0 + 1) ^ fsw) << 2)]);
+    if (APRE) {
+      const _Float16* Ah = reinterpret_cast<const _Float16*>(base);
+      const _Float16* Al = reinterpret_cast<const _Float16*>(base + A_BYTES / 2);
+      const int oa = frow * 32 + ((((2 * lh + sub)) ^ ((frow >> 2) & 3)) << 3);
+      f.ah = *reinterpret_cast<const v8h*>(&Ah[oa]);
+      f.al = *reinterpret_cast<const v8h*>(&Al[oa]);
+    } else {
+      const float* As = reinterpret_cast<const float*>(base);
+      const int c0 = 4 * lh + 2 * sub;   // 16-B chunk index of this lane's first 4 floats
+      f.v0 = *reinterpret_cast<const float4*>(&As[frow * 32 + ((c0 ^ fsw) << 2)]);
+      f.v1 = *reinterpret_cast<const float4*>(&As[frow * 32 + (((c0 + 1) ^ fsw) << 2)]);
+    }
     const _Float16* Bh = reinterpret_cast<const _Float16*>(base + A_BYTES);
     const _Float16* Bl = reinterpret_cast<const _Float16*>(base + A_BYTES + P_BYTES);
 #pragma unroll
@@ -169,6 +192,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
     }
   };
   auto frag_split = [&](Frag& f) {
+    if (APRE) return;
     float a8[8] = {f.v0.x, f.v0.y, f.v0.z, f.v0.w, f.v1.x, f.v1.y, f.v1.z, f.v1.w};
     if (GATE) {
       const float g8[8] = {f.g0.x, f.g0.y, f.g0.z, f.g0.w, f.g1.x, f.g1.y, f.g1.z, f.g1.w};
@@ -210,7 +234,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
       for (int g = 0; g < 3 * TN; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // 5 VALU
+        if (!APRE) __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // 5 VALU (the hi/lo split)
       }
       frag_mfma(f1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my DMAs have landed ...
@@ -278,11 +302,43 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
 #pragma unroll
       for (int r = 0; r < 16; ++r) rv[r] = 0.f;
     }
+    if (p.ys) {
+      // split-plane output: lanes c and c+1 trade halves so that every store is one 4-B pair of neighbouring columns
+      // (an f16 per lane would be twice the store instructions of the fp32 epilogue for half the bytes)
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      const bool odd = li & 1;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        unsigned own[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int r = 2 * q + e;
+          const float v = act_apply(acc[j][r] * p.out_scale + bv + rv[r], p.act);
+          _Float16 h, l;
+          split_f16(v, h, l);
+          h2 pr = {h, l};
+          own[e] = __builtin_bit_cast(unsigned, pr);
+        }
+        // even lane keeps row 2q and receives the partner's row 2q; odd lane keeps row 2q+1 and receives the partner's
+        const unsigned got = (unsigned)__shfl_xor((int)(odd ? own[0] : own[1]), 1, 64);
+        const unsigned mine = odd ? own[1] : own[0];
+        const h2 a = __builtin_bit_cast(h2, odd ? got : mine), b = __builtin_bit_cast(h2, odd ? mine : got);   // columns c0, c0+1
+        const int r = 2 * q + (odd ? 1 : 0);
+        const int row = rb0 + (r & 3) + 8 * (r >> 2);
+        const int c0 = col & ~1;
+        if (row < p.M) {      // Cout is a multiple of 32 for plane outputs (checked on the host): both columns exist
+          h2 hi = {a[0], b[0]}, lo = {a[1], b[1]};
+          *reinterpret_cast<h2*>(p.ys + (long)row * p.ldys + c0) = hi;
+          *reinterpret_cast<h2*>(p.ys + p.yplane + (long)row * p.ldys + c0) = lo;
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = rb0 + (r & 3) + 8 * (r >> 2);
-      const float v = acc[j][r] * p.out_scale + bv + rv[r];
-      if (row < p.M) p.y[(long)row * p.ldy + col] = act_apply(v, p.act);
+      const float v = act_apply(acc[j][r] * p.out_scale + bv + rv[r], p.act);
+      if (row < p.M) p.y[(long)row * p.ldy + col] = v;
     }
   }
 }
@@ -297,6 +353,38 @@ static void launch_bn(const ConvArgs& a, hipStream_t s) {
   if (a.gate) hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, true, true, NW>), g, b, 0, s, a);   // the gate implies 1x1x1
   else if (dense) hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, false, true, NW>), g, b, 0, s, a);
   else hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, false, false, NW>), g, b, 0, s, a);
+}
+
+// pre-split activations (mspi_gemm_sp_fwd): dense GEMM on rows, A = two f16 planes
+template <int BN, int NW>
+static void launch_sp(const ConvArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, false, true, NW, true>), dim3(a.nblocks), dim3(64 * NW), 0, s, a);
+}
+
+int launch_conv_sp(ConvArgs& a, long Ml, int bn, int rows, int* cfg, hipStream_t s) {
+  a.tiles_n = (int)((a.Cout + bn - 1) / bn);
+  const long nb = ((Ml + rows - 1) / rows) * a.tiles_n;
+  if (nb >= (1L << 31)) return -100;
+  a.nblocks = (int)nb;
+  *cfg = (rows << 16) | (bn << 4) | (rows == 256 ? 8 : 0) | (PREC_F16X3 << 1) | 4;
+  if (rows == 256) {
+    switch (bn) {
+      case 128: launch_sp<128, 8>(a, s); break;
+      case 192: launch_sp<192, 8>(a, s); break;
+      case 256: launch_sp<256, 8>(a, s); break;
+      default: return -100;
+    }
+    return 0;
+  }
+  switch (bn) {
+    case 64: launch_sp<64, 4>(a, s); break;
+    case 96: launch_sp<96, 4>(a, s); break;
+    case 128: launch_sp<128, 4>(a, s); break;
+    case 192: launch_sp<192, 4>(a, s); break;
+    case 256: launch_sp<256, 4>(a, s); break;
+    default: return -100;
+  }
+  return 0;
 }
 
 // 256 x BN tile, 8 waves (tile codes 12..14)

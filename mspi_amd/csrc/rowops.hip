@@ -17,7 +17,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         float* __restrict__ y, long ldy, long sNy,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, long M, int R, int C,
-                                                        int act, const float* __restrict__ table) {
+                                                        int act, const float* __restrict__ table,
+                                                        _Float16* __restrict__ ys, long ldys, long yplane) {
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int sub = lane % LPR;
@@ -68,7 +69,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const float4 t = *reinterpret_cast<const float4*>(tr + i * 4);
         o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
       }
-      *reinterpret_cast<float4*>(yr + i * 4) = o;
+      if (ys) {     // pre-split output for the f16x3 GEMM that consumes these rows (mspi_gemm_sp_fwd): dense rows
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const float a[4] = {o.x, o.y, o.z, o.w};
+        h4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { _Float16 hh, ll; split_f16(a[e], hh, ll); h[e] = hh; l[e] = ll; }
+        *reinterpret_cast<h4*>(ys + row * ldys + i * 4) = h;
+        *reinterpret_cast<h4*>(ys + yplane + row * ldys + i * 4) = l;
+      } else {
+        *reinterpret_cast<float4*>(yr + i * 4) = o;
+      }
     }
   }
 }
@@ -330,23 +341,24 @@ static inline unsigned grid_for(long total) {
 
 using namespace mspi;
 
-extern "C" int mspi_layernorm_fwd(const float* x, int64_t ldx, int64_t sNx, float* y, int64_t ldy, int64_t sNy,
-                                  const float* gamma, const float* beta, float eps, int32_t N, int32_t R, int32_t C,
-                                  int32_t act, const float* table, mspi_stream_t stream) {
-  MSPI_REQUIRE(x && y && gamma && beta, "mspi_layernorm_fwd: null argument");
+static int layernorm_impl(const float* x, int64_t ldx, int64_t sNx, float* y, int64_t ldy, int64_t sNy, void* planes, int64_t ldo,
+                          int64_t plane, const float* gamma, const float* beta, float eps, int32_t N, int32_t R, int32_t C,
+                          int32_t act, const float* table, mspi_stream_t stream, const char* who) {
+  MSPI_REQUIRE(x && (y || planes) && gamma && beta, "%s: null argument", who);
   const int64_t M = (int64_t)N * R;
-  MSPI_REQUIRE(N > 0 && R > 0 && C > 0 && (C & 3) == 0 && C <= LN_MAXC, "mspi_layernorm_fwd: C=%d must be a multiple of 4, <= %d",
-               C, LN_MAXC);
-  MSPI_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C && (sNx & 3) == 0 && (sNy & 3) == 0,
-               "mspi_layernorm_fwd: bad row/sample stride");
-  MSPI_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && (!table || aligned16(table)),
-               "mspi_layernorm_fwd: pointers must be 16-B aligned");
-  MSPI_REQUIRE(M < (1L << 31), "mspi_layernorm_fwd: too many rows");
+  MSPI_REQUIRE(N > 0 && R > 0 && C > 0 && (C & 3) == 0 && C <= LN_MAXC, "%s: C=%d must be a multiple of 4, <= %d", who, C, LN_MAXC);
+  MSPI_REQUIRE((ldx & 3) == 0 && ldx >= C && (sNx & 3) == 0, "%s: bad input row/sample stride", who);
+  MSPI_REQUIRE(planes || ((ldy & 3) == 0 && ldy >= C && (sNy & 3) == 0 && aligned16(y)), "%s: bad output row/sample stride", who);
+  MSPI_REQUIRE(!planes || ((ldo & 7) == 0 && ldo >= C && plane >= M * ldo && (plane & 7) == 0 && aligned16(planes)),
+               "%s: output planes need 16-B aligned rows and plane >= M*ld", who);
+  MSPI_REQUIRE(aligned16(x) && aligned16(gamma) && aligned16(beta) && (!table || aligned16(table)), "%s: pointers must be 16-B aligned", who);
+  MSPI_REQUIRE(M < (1L << 31), "%s: too many rows", who);
   const int nv = C / 4;
   hipStream_t s = (hipStream_t)stream;
 #define MSPI_LN(LPR, VPT)                                                                                             \
   hipLaunchKernelGGL((layernorm_kernel<LPR, VPT>), dim3((unsigned)((M + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), dim3(256), \
-                     0, s, x, (long)ldx, (long)sNx, y, (long)ldy, (long)sNy, gamma, beta, eps, (long)M, R, C, act, table)
+                     0, s, x, (long)ldx, (long)sNx, y, (long)ldy, (long)sNy, gamma, beta, eps, (long)M, R, C, act, table,    \
+                     (_Float16*)planes, (long)ldo, (long)plane)
   if (nv <= 16) MSPI_LN(16, 1);
   else if (nv <= 32) MSPI_LN(16, 2);
   else if (nv <= 64) MSPI_LN(16, 4);
@@ -355,7 +367,21 @@ extern "C" int mspi_layernorm_fwd(const float* x, int64_t ldx, int64_t sNx, floa
   else if (nv <= 512) MSPI_LN(64, 8);
   else MSPI_LN(64, 12);
 #undef MSPI_LN
-  return check_launch("mspi_layernorm_fwd");
+  return check_launch(who);
+}
+
+extern "C" int mspi_layernorm_fwd(const float* x, int64_t ldx, int64_t sNx, float* y, int64_t ldy, int64_t sNy,
+                                  const float* gamma, const float* beta, float eps, int32_t N, int32_t R, int32_t C,
+                                  int32_t act, const float* table, mspi_stream_t stream) {
+  return layernorm_impl(x, ldx, sNx, y, ldy, sNy, nullptr, 0, 0, gamma, beta, eps, N, R, C, act, table, stream, "mspi_layernorm_fwd");
+}
+
+extern "C" int mspi_layernorm_sp_fwd(const float* x, int64_t ldx, int64_t sNx, void* planes, int64_t ldo, int64_t plane,
+                                     const float* gamma, const float* beta, float eps, int32_t N, int32_t R, int32_t C,
+                                     int32_t act, mspi_stream_t stream) {
+  MSPI_REQUIRE(planes, "mspi_layernorm_sp_fwd: null output planes");
+  return layernorm_impl(x, ldx, sNx, nullptr, 0, 0, planes, ldo, plane, gamma, beta, eps, N, R, C, act, nullptr, stream,
+                        "mspi_layernorm_sp_fwd");
 }
 
 extern "C" int mspi_se_gate(const float* pool, int32_t rows, float inv_count, const float* w1, const float* b1,

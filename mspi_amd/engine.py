@@ -22,7 +22,7 @@ from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH, PREC_F1
 import os as _os
 DEFAULT_PREC = {"f32": PREC_F32, "f16x3": PREC_F16X3}[_os.environ.get("MSPI_GEMM_PREC", "f16x3")]
 
-__all__ = ["CL", "alloc", "pack_conv", "pack_dwconv", "PackedConv", "PackedDw", "conv", "dwconv", "maxpool",
+__all__ = ["CL", "SP", "alloc", "alloc_sp", "pack_conv", "pack_dwconv", "PackedConv", "PackedDw", "conv", "dwconv", "maxpool",
            "layernorm", "attention", "upsample", "rowgate", "logsumexp_sub", "mean_rows", "neg_cosine",
            "se_gate", "add", "fold_bn", "ACT_NONE", "ACT_RELU", "ACT_GELU", "ACT_SIGMOID", "ACT_SWISH"]
 
@@ -198,6 +198,41 @@ def alloc(N, T, H, W, Cc, device, ld=None):
         ld = rup4(Cc) if Cc > 1 else 1
     buf = torch.empty(N * T * H * W * ld, dtype=torch.float32, device=device)
     return CL(buf, 0, N, T, H, W, Cc, ld)
+
+
+SP_ENABLED = _os.environ.get("MSPI_PRESPLIT", "1") != "0"   # A/B switch: pre-split activations between LN / GEMM / GEMM
+
+
+class SP:
+    """Pre-split activation rows: two f16 planes [2][M][ld] (hi, lo) in one buffer -- what a producer's epilogue hands to
+    the f16x3 GEMM so that neither operand needs conversion work in the loop (include/mspi_hip.h, mspi_gemm_sp_fwd).
+    Same logical shape as a dense CL; only GEMM-shaped consumers (conv on 1x1x1 / Linear packs) accept it."""
+    __slots__ = ("buf", "N", "T", "H", "W", "C", "ld")
+
+    def __init__(self, buf, N, T, H, W, Cc, ld):
+        self.buf, self.N, self.T, self.H, self.W, self.C, self.ld = buf, N, T, H, W, Cc, ld
+
+    @property
+    def M(self):
+        return self.N * self.T * self.H * self.W
+
+    @property
+    def plane(self):
+        return self.M * self.ld
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
+
+
+def sp_supported(c):
+    """Channel counts the pre-split GEMM takes as its K: multiples of the 32-deep stage (then ldw == K)."""
+    return SP_ENABLED and DEFAULT_PREC == PREC_F16X3 and c % 32 == 0
+
+
+def alloc_sp(N, T, H, W, Cc, device):
+    assert Cc % 32 == 0
+    return SP(torch.empty(2 * N * T * H * W * Cc, dtype=torch.float16, device=device), N, T, H, W, Cc, Cc)
 
 
 def from_rows(t2d):
@@ -391,10 +426,75 @@ def _out_extent(T, H, W, k, s, p):
     return ((T + 2 * p[0] - k[0]) // s[0] + 1, (H + 2 * p[1] - k[1]) // s[1] + 1, (W + 2 * p[2] - k[2]) // s[2] + 1)
 
 
-def conv(x, pk, out=None, res=None, gate=None, act=None, tile=None):
+SP_TILES = (6, 7, 9, 10, 11, 12, 13, 14)      # mspi_gemm_sp_fwd: 128 x {128,64,96,192,256}, 256 x {256,192,128}
+
+
+def _conv_sp(x, pk, out, res, act, tile, sp_out):
+    """Dense GEMM on pre-split activation planes; result as fp32 rows (CL) or, sp_out, as planes for the next GEMM."""
+    lib = _lib.load()
+    _need_gpu(x.buf)
+    if pk.k != (1, 1, 1) or pk.stride != (1, 1, 1) or pk.pad != (0, 0, 0) or pk.prec != PREC_F16X3:
+        raise MspiError("conv: split-plane activations feed 1x1x1 / Linear f16x3 layers only")
+    if x.C != pk.cin_s or pk.ldw != x.C:
+        raise MspiError("conv: split-plane input has %d channels, weights were packed for %d (ldw %d)" % (x.C, pk.cin_s, pk.ldw))
+    dev = x.buf.device
+    if pk.w.device != dev:
+        raise MspiError("conv: packed weights live on %s, the input on %s" % (pk.w.device, dev))
+    M = x.M
+    if sp_out:
+        if res is not None or pk.cout_s % 32:
+            raise MspiError("conv: split-plane output takes no residual and needs Cout %% 32 == 0")
+        out = alloc_sp(x.N, x.T, x.H, x.W, pk.cout_s, dev)
+    else:
+        if out is None:
+            out = alloc(x.N, x.T, x.H, x.W, pk.cout, dev)
+        if out.M != M or out.Cs != pk.cout_s or not out.dense:
+            raise MspiError("conv: output CL does not match %d rows x %d channels" % (M, pk.cout))
+    if res is not None and (res.M != M or not res.dense):
+        raise MspiError("conv: residual rows %d != output rows %d (or residual not dense)" % (res.M, M))
+    d = ConvDesc()
+    d.N, d.T, d.H, d.W, d.C = x.N, x.T, x.H, x.W, x.C
+    d.kT = d.kH = d.kW = d.strT = d.strH = d.strW = 1
+    d.To, d.Ho, d.Wo, d.Cout = x.T, x.H, x.W, pk.cout_s
+    d.ldy = 0 if sp_out else out.ld
+    d.ldw, d.ldr = pk.ldw, (res.ld if res is not None else 0)
+    d.act = pk.act if act is None else act
+    d.prec, d.w_scale = pk.prec, pk.w_scale
+    args = (x.ptr, x.ld, x.plane, pk.w.data_ptr(), pk.bias.data_ptr() if pk.bias is not None else None,
+            res.ptr if res is not None else None, None if sp_out else out.ptr, out.ptr if sp_out else None,
+            out.ld if sp_out else 0, out.plane if sp_out else 0, _stream())
+
+    def launch(t):
+        d.tile = t
+        return lib.mspi_gemm_sp_fwd(C.byref(d), *args)
+
+    key = ("sp", M, x.C, pk.cout_s, res is not None, bool(sp_out))
+    choice = -1
+    if tile is not None:
+        choice = tile
+    elif AUTOTUNE["on"] and not torch.cuda.is_current_stream_capturing():
+        choice = AUTOTUNE["cache"].get(key)
+        if choice is None:
+            choice = _tune_conv(launch, key, [t for t in SP_TILES if t < 12 or M >= 4096])
+    elif key in AUTOTUNE["cache"]:
+        choice = AUTOTUNE["cache"][key]
+    with _Timed("conv_gemm", 2.0 * M * pk.cin * pk.cout, 4.0 * (M * pk.cin + M * pk.cout * (2 if res is not None else 1) + pk.cout * pk.cin),
+                "M=%d K=%d(1x%d) N=%d pre-split%s%s" % (M, pk.cin, pk.cin, pk.cout, " +res" if res is not None else "", " ->planes" if sp_out else "")) as tm:
+        check(launch(choice), "mspi_gemm_sp_fwd")
+        if Profiler.active is not None:
+            c = lib.mspi_conv_last_config()
+            tm.name = "conv_gemm<%d,%d,dma-presplit,f16x3>" % (c >> 16, (c >> 4) & 0xFFF)
+    return out
+
+
+def conv(x, pk, out=None, res=None, gate=None, act=None, tile=None, sp_out=False):
     """x: CL, or a raw 5-D [N,C,T,H,W] / 4-D [N,C,H,W] torch tensor with arbitrary strides.
     tile: force a kernel instantiation (MspiConvDesc.tile); None = autotune cache / library heuristic."""
     lib = _lib.load()
+    if isinstance(x, SP):
+        return _conv_sp(x, pk, out, res, act, tile, sp_out)
+    if sp_out:
+        raise MspiError("conv: split-plane output needs a split-plane input (mspi_gemm_sp_fwd)")
     d = ConvDesc()
     if isinstance(x, CL):
         _need_gpu(x.buf)
@@ -564,10 +664,18 @@ def se_gate(pool, inv_count, w1, b1, w2, b2, gate=None):
     return gate
 
 
-def layernorm(x, gamma, beta, eps, out=None, act=ACT_NONE, table=None):
-    """Rows of x -> rows of out; x and out may be token slabs (sample stride != dense)."""
+def layernorm(x, gamma, beta, eps, out=None, act=ACT_NONE, table=None, sp=False):
+    """Rows of x -> rows of out; x and out may be token slabs (sample stride != dense).
+    sp=True: the result as pre-split f16 planes (SP) for a following GEMM."""
     lib = _lib.load()
     _need_gpu(x.buf)
+    if sp:
+        assert out is None and table is None and x.C % 32 == 0
+        o = alloc_sp(x.N, x.T, x.H, x.W, x.C, x.buf.device)
+        with _Timed("layernorm", 8.0 * x.M * x.C, 8.0 * x.M * x.C, "M=%d C=%d ->planes" % (x.M, x.C)):
+            check(lib.mspi_layernorm_sp_fwd(x.ptr, x.ld, x.sN, o.ptr, o.ld, o.plane, gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                            x.N, x.T * x.H * x.W, x.C, act, _stream()), "mspi_layernorm_sp_fwd")
+        return o
     if out is None:
         out = alloc(x.N, x.T, x.H, x.W, x.C, x.buf.device)
     R = x.T * x.H * x.W
@@ -651,6 +759,9 @@ def mlp_tail(x, packed, ln, eps, res):
     """res + fc2(GELU(fc1(LayerNorm(x)))) with packed = pack_mlp_tail(...), ln = (gamma, beta)."""
     if packed[0] == "fused":
         return mlp(x, packed[1], res=res, ln=ln, eps=eps)
+    if sp_supported(x.C) and sp_supported(packed[1].cout_s) and packed[1].ldw == x.C and packed[2].ldw == packed[1].cout_s:
+        # LN -> planes, fc1 + GELU -> planes, fc2 (+res) -> fp32 rows: no operand is converted inside a GEMM loop
+        return conv(conv(layernorm(x, ln[0], ln[1], eps, sp=True), packed[1], sp_out=True), packed[2], res=res)
     return conv(conv(layernorm(x, ln[0], ln[1], eps), packed[1]), packed[2], res=res)
 
 

@@ -25,6 +25,9 @@ def profiler_name(k):
     if m:
         bm, bn, wm, wn, loader, prec = map(int, m.groups())
         return "conv_gemm<%d,%d,%s%s,%s>" % (bm, bn, "s" if loader else "v4", "w8" if wm * wn == 8 else "", "f16x3" if prec else "f32")
+    m = re.match(r"conv_gemm_dma_kernel<(\d+), (\w+), (\w+), (\d+)(?:, (\w+))?>", k)
+    if m:      # <BN, GATE, DENSE, NW[, APRE]>: rows = 32 * NW; APRE = pre-split activation planes
+        return "conv_gemm<%d,%s,%s,f16x3>" % (32 * int(m.group(4)), m.group(1), "dma-presplit" if m.group(5) == "true" else "dma")
     m = re.match(r"conv_gemm_dma_kernel<(\d+),", k)
     if m:
         return "conv_gemm<128,%s,dma,f16x3>" % m.group(1)

@@ -535,3 +535,40 @@ def test_permute_and_gated_sum(dev):
         cls = [E.CL(s_.to(dev).reshape(-1), 0, N, 1, R, 1, Cc, Cc) for s_ in srcs[:J]]
         out = E.gated_sum(cls, logit.to(dev))
         _close(out.buf.view(N, R, Cc), ref, 1e-6, "gated_sum J=%d" % J)
+
+
+@pytest.mark.parametrize("M,C,Hd", [(300, 96, 384), (6272, 384, 1536), (777, 64, 256), (4100, 320, 1280)])
+def test_presplit_ln_gemm_gemm_chain(dev, M, C, Hd):
+    """Pre-split activations: LayerNorm -> f16 hi/lo planes -> fc1 + GELU -> planes -> fc2 + residual, against torch fp32,
+    against the fp32-activation kernels (same arithmetic: equal to the last bits), and for every tile of mspi_gemm_sp_fwd."""
+    from mspi_amd import engine as E
+    from mspi_amd._lib import MspiError
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g) * 2 + 0.3
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    w1, b1 = torch.randn(Hd, C, generator=g) / math.sqrt(C), torch.randn(Hd, generator=g) * 0.1
+    w2, b2 = torch.randn(C, Hd, generator=g) / math.sqrt(Hd), torch.randn(C, generator=g) * 0.1
+    ref = x + F.linear(F.gelu(F.linear(F.layer_norm(x, (C,), gam, bet, 1e-6), w1, b1)), w2, b2)
+    xcl = E.CL(x.to(dev).view(-1), 0, 1, 1, 1, M, C, C)
+    p1 = E.pack_conv(w1, b1, act=E.ACT_GELU, device=dev)
+    p2 = E.pack_conv(w2, b2, device=dev)
+    ln = (gam.to(dev), bet.to(dev))
+    plain = E.conv(E.conv(E.layernorm(xcl, *ln, 1e-6), p1), p2, res=xcl)
+    _close(plain.buf.view(M, C), ref, 2e-5, "fp32-activation chain")
+    for t1 in E.SP_TILES:
+        for t2 in (E.SP_TILES if t1 == 6 else (10,)):
+            sp = E.layernorm(xcl, *ln, 1e-6, sp=True)
+            assert isinstance(sp, E.SP) and sp.buf.dtype == torch.float16
+            h = E.conv(sp, p1, sp_out=True, tile=t1)
+            y = E.conv(h, p2, res=xcl, tile=t2)
+            _close(y.buf.view(M, C), ref, 2e-5, "pre-split chain, tiles %d/%d" % (t1, t2))
+            assert (y.buf - plain.buf).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # planes reproduce the fp32 value to 22 bits
+    sp = E.layernorm(xcl, *ln, 1e-6, sp=True)
+    rec = sp.buf[: M * C].float() + sp.buf[M * C:].float()
+    want = F.layer_norm(x, (C,), gam, bet, 1e-6).reshape(-1)
+    assert (rec.cpu() - want).abs().max().item() < 3e-6 * want.abs().max().item() + 1e-6
+    with pytest.raises(MspiError, match="split-plane"):
+        E.conv(xcl, p1, sp_out=True)
+    with pytest.raises(MspiError, match="1x1x1"):
+        E.conv(sp, E.pack_conv(torch.randn(8, C, 1, 3, 3, generator=g), None, None, (1, 1, 1), (0, 1, 1), device=dev))
