@@ -161,7 +161,7 @@ class MultiScaleBlock(HipModule):
         heads, att = a.num_heads, a.dim_out
         hd = att // heads
         B = x.N
-        xn = E.layernorm(x, *pk["n1"], 1e-6)
+        xn = E.layernorm_for_gemm(x, *pk["n1"], 1e-6, *([pk["qkv"], pk["skip"]] if "skip" in pk else [pk["qkv"]]))
         qkv = E.conv(xn, pk["qkv"])                                   # [B,T,H,W, 3*att]: [q | k | v], heads inside
         q = E.dwconv(qkv.slice(0, att), pk["pq"])
         k = E.dwconv(qkv.slice(att, att), pk["pk"])

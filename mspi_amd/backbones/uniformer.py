@@ -124,7 +124,7 @@ class SABlock(HipModule):
     def run(self, x):
         pk, a = self.pk, self.attn
         x = E.dwconv(x, pk["pos"])
-        qkv = E.conv(E.layernorm(x, *pk["n1"], self.norm1.eps), pk["qkv"])
+        qkv = E.conv(E.layernorm_for_gemm(x, *pk["n1"], self.norm1.eps, pk["qkv"]), pk["qkv"])
         o = E.attention(qkv, x.N, x.T * x.H * x.W, a.num_heads, self.dim // a.num_heads, a.scale)
         x = E.conv(o, pk["proj"], res=x)
         return E.mlp_tail(x, pk["mlp"], pk["n2"], self.norm2.eps, res=x)

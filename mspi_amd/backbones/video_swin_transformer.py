@@ -137,7 +137,7 @@ class SwinTransformerBlock3D(HipModule):
         N, tok_idx, biasT, maskT, padded = self._geometry(pk, x.T, x.H, x.W)
         nwin = tok_idx.shape[0]
         if not padded:
-            xn = E.layernorm(x, *pk["n1"], 1e-5)
+            xn = E.layernorm_for_gemm(x, *pk["n1"], 1e-5, pk["qkv"])
             qkv = E.conv(xn, pk["qkv"])
             o = E.attention(qkv, x.N * nwin, N, a.num_heads, self.dim // a.num_heads, a.scale, biasT=biasT, maskT=maskT,
                             tok_idx=tok_idx)

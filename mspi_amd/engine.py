@@ -747,6 +747,15 @@ def mlp(x, pk, res=None, ln=None, eps=1e-6, out=None):
     return out
 
 
+def layernorm_for_gemm(x, gamma, beta, eps, *packs):
+    """LayerNorm whose result is consumed ONLY by the dense GEMMs `packs`: handed over as pre-split planes when every
+    consumer can take them (K a multiple of 32, K >= 256: below that the thin-GEMM kernels on fp32 rows are faster)."""
+    if sp_supported(x.C) and x.C >= 256 and all(p.k == (1, 1, 1) and p.stride == (1, 1, 1) and p.ldw == x.C and p.prec == PREC_F16X3
+                                                 for p in packs):
+        return layernorm(x, gamma, beta, eps, sp=True)
+    return layernorm(x, gamma, beta, eps)
+
+
 def pack_mlp_tail(fc1, fc2, out_scale=None):
     """LN -> Linear -> GELU -> Linear (+ residual) tail of a ConvNeXt / Swin / MViT block: the fused kernel where it
     applies (C in {96, 192}, f16x3), else the two GEMM packs.  Use with mlp_tail()."""

@@ -78,11 +78,10 @@ class Block(HipModule):
     def run(self, x, B, R):
         pk = self.pk
         dim = self.norm1.normalized_shape[0]
-        h = E.layernorm(x, *pk["n1"], 1e-5)
+        h = E.layernorm_for_gemm(x, *pk["n1"], 1e-5, pk["qkv"])
         o = E.attention(E.conv(h, pk["qkv"]), B, R, self.attn.num_heads, dim // self.attn.num_heads, self.attn.scale)
         x = E.conv(o, pk["proj"], res=x)
-        h = E.layernorm(x, *pk["n2"], 1e-5)
-        return E.conv(E.conv(h, pk["fc1"]), pk["fc2"], res=x)
+        return E.mlp_tail(x, ("split", pk["fc1"], pk["fc2"]), pk["n2"], 1e-5, res=x)
 
 
 class SyncBlock(HipModule):
