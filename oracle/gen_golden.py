@@ -332,6 +332,19 @@ def case_uniformer_backbone(seed=0):
         _save("uniformer_backbone_%d" % size, seed=seed, size=size, batch=B, sd_crc=T.sd_checksum(sd), **_feat_fixture(feats))
 
 
+def case_av_slowfast_224():
+    """BASELINE configs[2]'s model at full frame size (one clip; Wa = 300)."""
+    _model_case("slowfast4x16", "AudioVisualSaliencyModel", 224, 1, 300, 0, "av_slowfast_224")
+
+
+def case_av_uniformer_224():
+    _model_case("uniformerb", "AudioVisualSaliencyModel", 224, 1, 111, 0, "av_uniformer_224")
+
+
+def case_av_s3d_224():
+    _model_case("s3d", "AudioVisualSaliencyModel", 224, 1, 300, 0, "av_s3d_224")
+
+
 def case_av_uniformer_64():
     _model_case("uniformerb", "AudioVisualSaliencyModel", 64, 2, 111, 0, "av_uniformer_64")
 

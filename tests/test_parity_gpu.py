@@ -138,7 +138,8 @@ def _build(g, name, cls, dev):
 
 @pytest.mark.parametrize("case,name", [("av_x3dl_64", "x3dl"), ("av_x3dl_224", "x3dl"), ("av_slowfast_64", "slowfast4x16"),
                                        ("av_mvit_224", "mvitv2s"), ("av_swin_s_224", "videoswins"), ("av_s3d_64", "s3d"),
-                                       ("av_uniformer_64", "uniformerb"), ("av_morphmlp_224", "morphmlps")])
+                                       ("av_uniformer_64", "uniformerb"), ("av_morphmlp_224", "morphmlps"),
+                                       ("av_slowfast_224", "slowfast4x16"), ("av_uniformer_224", "uniformerb"), ("av_s3d_224", "s3d")])
 def test_audio_visual_model_vs_golden(dev, golden_dir, case, name):
     g = _g(golden_dir, case)
     cfg, m, clips, audio = _build(g, name, "AudioVisualSaliencyModel", dev)
