@@ -23,11 +23,18 @@ for N, T, H, W, C, k, pad, pool in SHAPES:
     pk = E.pack_dwconv(w, torch.randn(C, generator=g), None, (1, 1, 1), pad, E.ACT_NONE, device=dev)
     for _ in range(3):
         E.dwconv(x, pk, pool=pool)
+    # 20 launches inside ONE hipGraph (eager Python launches can be further apart than these kernels are long)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=st):
+        for _ in range(20):
+            E.dwconv(x, pk, pool=pool)
+    gr.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(20):
-        E.dwconv(x, pk, pool=pool)
+    gr.replay()
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
