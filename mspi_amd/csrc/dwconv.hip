@@ -24,6 +24,7 @@ struct DwArgs {
   int act;
   int CV;          // C / 4
   long per_sample; // To*Ho*Wo*CV
+  int unit_xcd;    // one unit (sample / sample x channel group) per XCD (A/B switch MSPI_DW_UNIT_XCD=0)
 };
 
 // XCD-aware bijective block remap (same as the GEMM): consecutive logical blocks -- neighbouring output
@@ -34,10 +35,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// One work UNIT (a sample, or a sample x channel group) per XCD: workgroups are dealt to the 8 XCDs round-robin in linear
+// launch order, so workgroup L of a group of eight units takes unit L % 8 and block L / 8 of it.  An XCD then streams its
+// unit front to back: the window re-reads stay in ITS L2 and HBM sees every record once -- against 1.6-2.3x the algorithmic
+// bytes (PMC) when every unit is cut into eight position slices that each need their neighbours' halo.  Needs the unit
+// count to be a multiple of 8; otherwise the per-unit slice remap above.
+__device__ __forceinline__ void unit_per_xcd(long L, int nblk, int units, int& unit, int& lb, int enabled) {
+  if (enabled && (units & 7) == 0) {
+    const long q = L / (8L * nblk), r = L - q * 8L * nblk;
+    unit = (int)(q * 8 + (r & 7));
+    lb = (int)(r >> 3);
+  } else {
+    unit = (int)(L / nblk);
+    lb = xcd_remap((int)(L - (long)unit * nblk), nblk);
+  }
+}
+
 template <bool IS_MAX>
 __global__ __launch_bounds__(256) void dw_kernel(const DwArgs p) {
-  const int n = blockIdx.y;
-  const long idx = (long)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+  int n, lb0;
+  unit_per_xcd((long)blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, n, lb0, p.unit_xcd);
+  const long idx = (long)lb0 * 256 + threadIdx.x;
   if (idx < p.per_sample) {
     const int cv = (int)(idx % p.CV);
     long pos = idx / p.CV;
@@ -98,9 +116,9 @@ __global__ __launch_bounds__(256) void dw_kernel(const DwArgs p) {
 template <int KW, int SWS, int SW, bool POOL>
 __global__ __launch_bounds__(256) void dw_strip_kernel(const DwArgs p) {
   __shared__ float4 stage[POOL ? 256 : 1];
-  const int n = blockIdx.y;
   const int nblk = gridDim.x;
-  const int lb = xcd_remap(blockIdx.x, nblk);
+  int n, lb;
+  unit_per_xcd((long)blockIdx.y * nblk + blockIdx.x, nblk, gridDim.y, n, lb, p.unit_xcd);
   const long idx0 = (long)lb * 256;
   const long idx = idx0 + threadIdx.x;
   const int S = (p.Wo + SW - 1) / SW;
@@ -204,9 +222,10 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const DwArgs p, int CG, in
   float4* wl = dw_smem;
   float4* stage = dw_smem + taps * CG;
   const int tid = threadIdx.x;
-  const int n = blockIdx.z, g = blockIdx.y;
   const int nblk = gridDim.x;
-  const int lb = xcd_remap(blockIdx.x, nblk);
+  int unit, lb;      // unit = (sample, channel group)
+  unit_per_xcd(((long)blockIdx.z * gridDim.y + blockIdx.y) * nblk + blockIdx.x, nblk, gridDim.y * gridDim.z, unit, lb, p.unit_xcd);
+  const int n = unit / gridDim.y, g = unit - n * gridDim.y;
   for (int i = tid; i < taps * CG; i += 256) {
     const int tap = i / CG, c = i - tap * CG;
     wl[i] = *reinterpret_cast<const float4*>(p.w + (long)tap * p.C + (g * CG + c) * 4);
@@ -320,7 +339,7 @@ __global__ __launch_bounds__(256) void dw_lds_kernel(const DwArgs p, int CG, int
   const int tid = threadIdx.x;
   const int n = blockIdx.z, g = blockIdx.y;
   const int nblk = gridDim.x;
-  const int lb = xcd_remap(blockIdx.x, nblk);
+  const int lb = xcd_remap(blockIdx.x, nblk);   // (unit-per-XCD measured slower here: a unit is a <= 128-B slice of every pixel)
   const int tw = lb % nTw, th = (lb / nTw) % nTh, tt = lb / (nTw * nTh);
   const int to0 = tt * TT, ho0 = th * TH, wo0 = tw * TWp;
   const int t0 = to0 - p.padT, h0 = ho0 - p.padH, w0 = wo0 - p.padW;
@@ -507,6 +526,8 @@ static int fill_args(const MspiDwConvDesc* d, DwArgs& a, const char* who) {
   a.To = To; a.Ho = Ho; a.Wo = Wo; a.act = d->act;
   a.CV = d->C / 4;
   a.per_sample = (long)To * Ho * Wo * a.CV;
+  static const int unit_xcd = getenv("MSPI_DW_UNIT_XCD") ? atoi(getenv("MSPI_DW_UNIT_XCD")) : 1;
+  a.unit_xcd = unit_xcd;
   MSPI_REQUIRE((a.per_sample + 255) / 256 < (1L << 31) && d->N < 65536, "%s: grid too large", who);
   return MSPI_OK;
 }
