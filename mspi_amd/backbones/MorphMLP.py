@@ -10,7 +10,7 @@ takes the bare clip tensor (model/model_utils.py:527-528).
 The model is channels-last upstream ([B,T,H,W,C]) -- exactly this engine's activation layout.  A MorphFC layer is a
 Linear over tokens regrouped by `reshape -> permute -> reshape` (chunks of `segment_dim` neighbouring positions along
 W, along H, or the T frames, times a 1/segment_dim slice of the channels).  Each regrouping and its inverse is ONE
-strided-gather launch (`mspi_permute_fwd`; the index maps are the `*_dims` functions below, checked against the
+strided-gather launch (`mspi_permute_fwd`; the index maps are the `*_gather` / `*_scatter` functions below, checked against the
 reference's tensor expressions on the host), every Linear is the GEMM kernel, the branch re-weighting
 softmax(reweight(mean(h+w+c))) . (h, w, c) is one element-wise launch (`mspi_gated_sum_fwd`), and
 norm2 -> fc1 -> GELU -> fc2 -> +x is the usual MLP tail.
