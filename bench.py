@@ -58,7 +58,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(sd, cfg, name, clips, audio, budget_s=25.0):
+def cpu_baseline(sd, cfg, name, clips, audio, budget_s=float(os.environ.get("MSPI_BENCH_CPU_BUDGET_S", "25"))):
     """The oracle (CPU restatement pinned to the reference) on the host cores of this box: B=1 clips,
     repeated until ~budget_s of CPU work.  A reported baseline, not the target."""
     from oracle import restate as R

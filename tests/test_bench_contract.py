@@ -1,0 +1,40 @@
+"""bench.py's one-line JSON contract (driver-facing): keys, types, roofline / cpu_baseline objects, the multi-rank switch."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_line_schema(dev):
+    env = dict(os.environ, MSPI_BENCH_CPU_BUDGET_S="4")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--stream-layouts", "2"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, "bench.py must print exactly one line on stdout"
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "clips_per_sec" and d["unit"] == "clips/s" and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"] and d["value"] > 50
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "traffic" in rf and rf["avg_launch_us"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "clips/s" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
