@@ -374,6 +374,44 @@ def case_av_morphmlp_224():
     _model_case("morphmlps", "AudioVisualSaliencyModel", 224, 1, 111, 0, "av_morphmlp_224")
 
 
+def case_av_x3dl_64_units():
+    """Unit-level outputs of the reference model: forward hooks on the reference's own sub-modules during the
+    av_x3dl_64 forward -- image encoder (o1, o0), Adapter masks, audio ResNet-18, SyncBlock tokens, the four lateral layers
+    (after SA gating for 0-2 the hook sits on sa_k) and the readout stack -- stored as strided samples (_feat_fixture)."""
+    from mspi_amd.model import model_utils as pm
+    name, size, B, wa, seed = "x3dl", 64, 2, 111, 0
+    nvt, aud_tok = 16 * (size // 32) ** 2, 36
+    pcfg = T.make_cfg(name, num_aud_tokens=aud_tok, num_vis_tokens=nvt)
+    prod = T.seeded(lambda: pm.AudioVisualSaliencyModel(pcfg), seed)
+    sd = prod.state_dict()
+    ref = build_reference_model(name, "AudioVisualSaliencyModel", num_vis_tokens=nvt)
+    ref.load_state_dict(sd, strict=True)
+    got = {}
+
+    def hook(key):
+        def fn(mod, inp, out):
+            got[key] = [o.detach().clone() for o in out] if isinstance(out, (tuple, list)) else [out.detach().clone()]
+        return fn
+
+    names = ["image_encoder", "adapter", "audnet", "aud_vis_sync_block", "latlayer_0", "latlayer_1", "latlayer_2", "latlayer_3",
+             "sa_0", "sa_1", "sa_2", "readout"]
+    hs = [getattr(ref, n).register_forward_hook(hook(n)) for n in names]
+    clips, audio = T.synth_inputs(B, 16, size, size, Wa=wa, seed=seed)
+    with torch.no_grad():
+        out, loss = ref(clips, audio)
+    for h in hs:
+        h.remove()
+    tensors, keys = [], []
+    for n in names:
+        for i, t in enumerate(got[n]):
+            tensors.append(t.float())
+            keys.append("%s.%d" % (n, i))
+    fx = _feat_fixture(tensors, max_elems=1 << 12)
+    _save("av_x3dl_64_units", seed=seed, size=size, batch=B, wa=wa, num_vis_tokens=nvt, num_aud_tokens=aud_tok,
+          sd_crc=T.sd_checksum(sd), keys=np.array(keys), out=out, **fx)
+    print("  hooked:", ", ".join("%s%s" % (k, tuple(t.shape)) for k, t in zip(keys, tensors)))
+
+
 def c2_name_corpus():
     """caffe2 blob names of the ResNet / SlowFast / X3D / non-local model-zoo families (R50 depths), plus optimizer
     blobs and a few names that match no rule -- the input side of tests/golden/c2_names.json."""

@@ -480,17 +480,24 @@ def readout(sd, p, x):
     return _conv3(sd, p + ".12", x, 1, (0, 1, 1))
 
 
-def decode(sd, feats, masks, lateral_bool, lateral_stride):
-    """Top-down fusion + readout, model/model_utils.py:561-572."""
+def decode(sd, feats, masks, lateral_bool, lateral_stride, trace=None):
+    """Top-down fusion + readout, model/model_utils.py:561-572.  trace: dict that receives the sub-module outputs the
+    reference's forward hooks see (latlayer_k, sa_k, readout)."""
     v1, v2, v3, v4 = feats
     s3 = latlayer(sd, "latlayer_3", v4, lateral_bool[3], lateral_stride[3])
     s0 = latlayer(sd, "latlayer_0", v1, lateral_bool[0], lateral_stride[0])
     s1 = latlayer(sd, "latlayer_1", v2, lateral_bool[1], lateral_stride[1])
     s2 = latlayer(sd, "latlayer_2", v3, lateral_bool[2], lateral_stride[2])
-    s2 = sa_gate(sd, "sa_2", s2, masks, 1) + _up(s3, 2)
-    s1 = sa_gate(sd, "sa_1", s1, masks, 2) + _up(s2, 2) + _up(s3, 4)
-    s0 = sa_gate(sd, "sa_0", s0, masks, 4) + _up(s1, 2) + _up(s2, 4) + _up(s3, 8)
+    g2, g1, g0 = sa_gate(sd, "sa_2", s2, masks, 1), sa_gate(sd, "sa_1", s1, masks, 2), sa_gate(sd, "sa_0", s0, masks, 4)
+    if trace is not None:
+        trace.update({"latlayer_0.0": s0, "latlayer_1.0": s1, "latlayer_2.0": s2, "latlayer_3.0": s3,
+                      "sa_0.0": g0, "sa_1.0": g1, "sa_2.0": g2})
+    s2 = g2 + _up(s3, 2)
+    s1 = g1 + _up(s2, 2) + _up(s3, 4)
+    s0 = g0 + _up(s1, 2) + _up(s2, 4) + _up(s3, 8)
     out = readout(sd, "readout", torch.cat([s0, _up(s1, 2), _up(s2, 4), _up(s3, 8)], 1))
+    if trace is not None:
+        trace["readout.0"] = out
     out = out.squeeze(1).squeeze(1)
     return out - torch.logsumexp(out, dim=(1, 2), keepdim=True)
 
@@ -676,8 +683,9 @@ BACKBONES["mvitv2s"] = lambda sd, x, prefix: mvit_forward(sd, x[0], MVIT_S_ARCH,
 BACKBONES["videoswins"] = lambda sd, x, prefix: swin_forward(sd, x, prefix)
 
 
-def audio_visual_forward(sd, clips, audios, name, lateral_bool, lateral_stride, num_frames=16):
-    """AudioVisualSaliencyModel.forward, model/model_utils.py:520-574.  Returns (log-prob map, loss)."""
+def audio_visual_forward(sd, clips, audios, name, lateral_bool, lateral_stride, num_frames=16, trace=None):
+    """AudioVisualSaliencyModel.forward, model/model_utils.py:520-574.  Returns (log-prob map, loss).
+    trace: dict that receives the outputs of the sub-modules (keys as the reference's module names + output index)."""
     B = clips.shape[0]
     frames = clips.permute(0, 2, 1, 3, 4).reshape(B * clips.shape[2], clips.shape[1], *clips.shape[3:])
     o1, o0 = static_saliency_encoder(sd, frames)
@@ -691,7 +699,9 @@ def audio_visual_forward(sd, clips, audios, name, lateral_bool, lateral_stride, 
     vis_emb = _projector(sd, "vis_projector", vis_fea.mean((2, 3, 4)))
     aud_emb = _projector(sd, "aud_projector", aud_fea.mean(2))
     loss = (_D(_predictor(sd, "mlp_vis", vis_emb), aud_emb) + _D(_predictor(sd, "mlp_aud", aud_emb), vis_emb)) * 0.5
-    out = decode(sd, (v1, v2, v3, torch.cat([v4, vis_fea], 1)), masks, lateral_bool, lateral_stride)
+    if trace is not None:
+        trace.update({"image_encoder.0": o1, "image_encoder.1": o0, "adapter.0": masks, "audnet.0": aud, "aud_vis_sync_block.0": x})
+    out = decode(sd, (v1, v2, v3, torch.cat([v4, vis_fea], 1)), masks, lateral_bool, lateral_stride, trace)
     return out, loss
 
 

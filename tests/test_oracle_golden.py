@@ -217,3 +217,18 @@ def test_visual_model(golden_dir):
     with torch.no_grad():
         out, zero = R.visual_forward(sd, clips, "x3dl", cfg.MODEL.LATERAL_BOOL, cfg.MODEL.LATERAL_STRIDE)
     assert zero == 0 and _err(out, g["out"]) <= 5e-5
+
+
+def test_unit_level_outputs_against_reference_hooks(golden_dir):
+    """the oracle's sub-module outputs (image encoder, Adapter, audio ResNet, SyncBlock, lateral layers, SA
+    gates, readout) against what forward hooks on the REFERENCE's own sub-modules recorded during the same forward."""
+    g = _g(golden_dir, "av_x3dl_64_units")
+    cfg, sd, clips, audio = _model(g, "x3dl", "AudioVisualSaliencyModel")
+    tr = {}
+    with torch.no_grad():
+        out, _ = R.audio_visual_forward(sd, clips, audio, "x3dl", cfg.MODEL.LATERAL_BOOL, cfg.MODEL.LATERAL_STRIDE, trace=tr)
+    keys = [str(k) for k in g["keys"]]
+    assert len(keys) == 13 and set(keys) == set(tr)
+    for i, k in enumerate(keys):
+        assert T.feature_error(tr[k], g, "v%d" % (i + 1)) <= 2e-6, k
+    assert _err(out, g["out"]) <= 5e-5
