@@ -412,6 +412,117 @@ def case_av_x3dl_64_units():
     print("  hooked:", ", ".join("%s%s" % (k, tuple(t.shape)) for k, t in zip(keys, tensors)))
 
 
+def _hook_outputs(ref, names):
+    got = {}
+
+    def hook(key):
+        def fn(mod, inp, out):
+            outs = out if isinstance(out, (tuple, list)) else [out]
+            for i, o in enumerate(outs):
+                if torch.is_tensor(o):
+                    got["%s.%d" % (key, i) if len(outs) > 1 else key] = o.detach().clone().float()
+        return fn
+
+    mods = dict(ref.named_modules())
+    hs = [mods[n].register_forward_hook(hook(n)) for n in names]
+    return got, hs
+
+
+def case_backbone_units(seed=0):
+    """Unit-level outputs inside the four BASELINE backbones, recorded by forward hooks on the reference's
+    own sub-modules: X3D stem; SlowFast stems, both pathways of s2-s4 before each fusion, the fused slow pathway after s1;
+    every MViTv2-S block (the seven distinct (stride_q, stride_kv, width) cases among them); every Video-Swin-T block
+    (plain and shifted windows) and PatchMerging output."""
+    from mspi_amd.config import cfg as pcfg
+    from mspi_amd.backbones.X3D import X3D
+    from mspi_amd.backbones.sf import SlowFast
+    from mspi_amd.backbones.MViT import MViT
+    from mspi_amd.backbones.video_swin_transformer import SwinTransformer3D
+    out = {}
+
+    def record(tag, ref, names, run, ora_trace):
+        got, hs = _hook_outputs(ref, names)
+        with torch.no_grad():
+            run()
+        for h in hs:
+            h.remove()
+        keys = sorted(got)
+        assert set(keys) == set(ora_trace), (sorted(set(keys) ^ set(ora_trace)))
+        _check_restatement("%s units" % tag, [got[k] for k in keys], [ora_trace[k].reshape(got[k].shape) for k in keys], 5e-5)
+        fx = _feat_fixture([got[k] for k in keys], max_elems=1 << 11)
+        out.update({"%s_%s" % (tag, k): v for k, v in fx.items()})
+        out[tag + "_keys"] = np.array(keys)
+
+    # X3D-L, 64x64
+    prod = T.seeded(lambda: X3D(pcfg.MODEL.X3D.PATH_CFG), seed)
+    sd = prod.state_dict()
+    rcfg = rh.with_config("x3dl")
+    from backbones.X3D import X3D as RefX3D
+    ref = RefX3D(path_to_config=rcfg.MODEL.X3D.PATH_CFG).eval()
+    ref.load_state_dict(sd, strict=True)
+    clips, _ = T.synth_inputs(2, 16, 64, 64, seed=seed)
+    tr = {}
+    with torch.no_grad():
+        R.x3d_forward(sd, clips, trace=tr)
+    record("x3dl", ref, ["s1"], lambda: ref([clips]), {"s1": tr["s1"]})
+    out["x3dl_crc"] = T.sd_checksum(sd)
+    # SlowFast, 64x64
+    prod = T.seeded(lambda: SlowFast(pcfg.MODEL.SLOWFAST.PATH_CFG), seed)
+    sd = prod.state_dict()
+    rcfg = rh.with_config("slowfast4x16")
+    from backbones.sf import SlowFast as RefSF
+    ref = RefSF(path_to_config=rcfg.MODEL.SLOWFAST.PATH_CFG).eval()
+    ref.load_state_dict(sd, strict=True)
+    packed = R.pack_clips("slowfast4x16", clips)
+    tr = {}
+    with torch.no_grad():
+        R.slowfast_forward(sd, packed, trace=tr)
+    tr = {k: v for k, v in tr.items()}
+    tr["s1_fuse.0"] = tr["s1_fuse.0"]
+    record("slowfast", ref, ["s1", "s1_fuse", "s2", "s3", "s4"], lambda: ref(packed),
+           {"s1.0": tr["s1.0"], "s1.1": tr["s1.1"], "s1_fuse.0": tr["s1_fuse.0"], "s1_fuse.1": tr["s1.1"],
+            "s2.0": tr["s2.0"], "s2.1": tr["s2.1"], "s3.0": tr["s3.0"], "s3.1": tr["s3.1"], "s4.0": tr["s4.0"], "s4.1": tr["s4.1"]})
+    out["slowfast_crc"] = T.sd_checksum(sd)
+    # MViTv2-S, 224x224 (its relative-position tables are sized for 224)
+    prod = T.seeded(lambda: MViT(pcfg.MODEL.MVIT2.PATH_CFG), seed)
+    sd = prod.state_dict()
+    rcfg = rh.with_config("mvitv2s")
+    from backbones.MViT import MViT as RefMViT
+    ref = RefMViT(path_to_configs=rcfg.MODEL.MVIT2.PATH_CFG).eval()
+    ref.load_state_dict(sd, strict=True)
+    clips224, _ = T.synth_inputs(1, 16, 224, 224, seed=seed)
+    tr = {}
+    with torch.no_grad():
+        R.mvit_forward(sd, clips224, R.MVIT_S_ARCH, trace=tr)
+    got, hs = _hook_outputs(ref, ["blocks.%d" % i for i in range(16)])
+    with torch.no_grad():
+        ref([clips224])
+    for h in hs:
+        h.remove()
+    got = {".".join(k.split(".")[:2]): v for k, v in got.items()}       # a block returns (x, thw): "blocks.N.0" -> "blocks.N"
+    keys = sorted(got, key=lambda k: int(k.split(".")[1]))
+    _check_restatement("mvit units", [got[k] for k in keys], [tr[k] for k in keys], 5e-5)
+    fx = _feat_fixture([got[k] for k in keys], max_elems=1 << 11)
+    out.update({"mvit_%s" % k: v for k, v in fx.items()})
+    out["mvit_keys"] = np.array(keys)
+    out["mvit_crc"] = T.sd_checksum(sd)
+    # Video-Swin-T, 224x224
+    prod = T.seeded(lambda: SwinTransformer3D(depths=[2, 2, 6, 2]), seed)
+    sd = prod.state_dict()
+    rh.with_config("videoswins")
+    from backbones.video_swin_transformer import SwinTransformer3D as RefSwin
+    ref = RefSwin(depths=[2, 2, 6, 2])
+    ref.eval()
+    ref.load_state_dict(sd, strict=True)
+    tr = {}
+    with torch.no_grad():
+        R.swin_forward(sd, clips224, trace=tr)
+    names = [k for k in tr]
+    record("swin", ref, names, lambda: ref(clips224), tr)
+    out["swin_crc"] = T.sd_checksum(sd)
+    _save("backbone_units", seed=seed, **out)
+
+
 def c2_name_corpus():
     """caffe2 blob names of the ResNet / SlowFast / X3D / non-local model-zoo families (R50 depths), plus optimizer
     blobs and a few names that match no rule -- the input side of tests/golden/c2_names.json."""

@@ -100,9 +100,11 @@ def res_stage(sd, p, x, pathway, stride, trans):
     return x
 
 
-def x3d_forward(sd, clips, prefix=""):
-    """backbones/X3D.py:236-246: s1..s5, features = outputs of s2..s5."""
+def x3d_forward(sd, clips, prefix="", trace=None):
+    """backbones/X3D.py:236-246: s1..s5, features = outputs of s2..s5.  trace: dict receiving sub-module outputs."""
     x = x3d_stem(sd, prefix + "s1.pathway0_stem", clips)
+    if trace is not None:
+        trace["s1"] = x
     feats = []
     for s in ("s2", "s3", "s4", "s5"):
         x = res_stage(sd, prefix + s, x, 0, 2, x3d_transform)
@@ -125,17 +127,23 @@ def fuse_fast_to_slow(sd, p, xs, xf, alpha):
     return torch.cat([xs, f], 1)
 
 
-def slowfast_forward(sd, x, prefix="", alpha=4):
+def slowfast_forward(sd, x, prefix="", alpha=4, trace=None):
     """backbones/sf.py:360-385; features = slow pathway after s2/s3/s4 fusion and after s5."""
     p = prefix
     xs, xf = basic_stem(sd, p + "s1.pathway0_stem", x[0]), basic_stem(sd, p + "s1.pathway1_stem", x[1])
+    if trace is not None:
+        trace["s1.0"], trace["s1.1"] = xs, xf
     xs = fuse_fast_to_slow(sd, p + "s1_fuse", xs, xf, alpha)
+    if trace is not None:
+        trace["s1_fuse.0"] = xs
     feats = []
     for i, s in enumerate(("s2", "s3", "s4", "s5")):
         stride = 1 if i == 0 else 2
         xs = res_stage(sd, p + s, xs, 0, stride, bottleneck_transform)
         if i < 3:
             xf = res_stage(sd, p + s, xf, 1, stride, bottleneck_transform)
+            if trace is not None:
+                trace[s + ".0"], trace[s + ".1"] = xs, xf
             xs = fuse_fast_to_slow(sd, p + s + "_fuse", xs, xf, alpha)
         feats.append(xs)
     return feats
@@ -200,7 +208,7 @@ def mvit_block(sd, p, x, thw, heads, stride_q, stride_kv):
     return x, q_thw
 
 
-def mvit_forward(sd, clips, arch, prefix=""):
+def mvit_forward(sd, clips, arch, prefix="", trace=None):
     """backbones/MViT.py:2016-2076.  arch: per block (heads, stride_q, stride_kv); taps after blocks 0,2,13,15."""
     p = prefix
     w = sd[p + "patch_embed.proj.weight"]
@@ -210,6 +218,8 @@ def mvit_forward(sd, clips, arch, prefix=""):
     feats = []
     for i, (heads, sq, skv) in enumerate(arch["blocks"]):
         x, thw = mvit_block(sd, "%sblocks.%d" % (p, i), x, thw, heads, sq, skv)
+        if trace is not None:
+            trace["blocks.%d" % i] = x
         if i in (0, 2, 13, 15):
             feats.append(x.transpose(1, 2).reshape(x.shape[0], -1, thw[0], thw[1], thw[2]))
     return feats
@@ -274,7 +284,7 @@ def swin_block(sd, p, x, heads, window, shift, mask):
     return x + _lin(sd, p + ".mlp.fc2", F.gelu(_lin(sd, p + ".mlp.fc1", _ln(sd, p + ".norm2", x))))
 
 
-def swin_forward(sd, clips, prefix="", window=(8, 7, 7), heads=(3, 6, 12, 24)):
+def swin_forward(sd, clips, prefix="", window=(8, 7, 7), heads=(3, 6, 12, 24), trace=None):
     """SwinTransformer3D.forward, backbones/video_swin_transformer.py:692-708: every stage's pre-merge output."""
     p = prefix
     w = sd[p + "patch_embed.proj.weight"]
@@ -290,12 +300,16 @@ def swin_forward(sd, clips, prefix="", window=(8, 7, 7), heads=(3, 6, 12, 24)):
         while "%slayers.%d.blocks.%d.norm1.weight" % (p, li, bi) in sd:
             x = swin_block(sd, "%slayers.%d.blocks.%d" % (p, li, bi), x, heads[li], window,
                            (0, 0, 0) if bi % 2 == 0 else shift, mask)
+            if trace is not None:
+                trace["layers.%d.blocks.%d" % (li, bi)] = x
             bi += 1
         feats.append(x.permute(0, 4, 1, 2, 3))
         q = "%slayers.%d.downsample" % (p, li)
         if q + ".reduction.weight" in sd:   # PatchMerging :296-329 (even grids)
             x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
             x = _lin(sd, q + ".reduction", _ln(sd, q + ".norm", x))
+            if trace is not None:
+                trace["layers.%d.downsample" % li] = x
         li += 1
     return feats
 

@@ -232,3 +232,52 @@ def test_unit_level_outputs_against_reference_hooks(golden_dir):
     for i, k in enumerate(keys):
         assert T.feature_error(tr[k], g, "v%d" % (i + 1)) <= 2e-6, k
     assert _err(out, g["out"]) <= 5e-5
+
+
+def _unit_check(g, tag, trace, rename=None, tol=2e-6):
+    keys = [str(k) for k in g[tag + "_keys"]]
+    sub = {k[len(tag) + 1:]: g[k] for k in g.files if k.startswith(tag + "_v")}
+    for i, k in enumerate(keys):
+        t = trace[rename(k) if rename else k]
+        shape = tuple(int(v) for v in sub["v%d_shape" % (i + 1)])
+        assert T.feature_error(t.reshape(shape), sub, "v%d" % (i + 1)) <= tol, "%s %s" % (tag, k)
+    return len(keys)
+
+
+def test_backbone_unit_level_outputs_against_reference_hooks(golden_dir):
+    """sub-module outputs inside the four BASELINE backbones against forward hooks on the reference's own
+    modules -- X3D stem, SlowFast stems / pathways / first fusion, all 16 MViTv2-S blocks, all Swin-T blocks + PatchMerging."""
+    from mspi_amd.backbones.MViT import MViT
+    from mspi_amd.backbones.X3D import X3D
+    from mspi_amd.backbones.sf import SlowFast
+    from mspi_amd.backbones.video_swin_transformer import SwinTransformer3D
+    from mspi_amd.config import cfg
+    g = _g(golden_dir, "backbone_units")
+    seed = int(g["seed"])
+    clips, _ = T.synth_inputs(2, 16, 64, 64, seed=seed)
+    clips224, _ = T.synth_inputs(1, 16, 224, 224, seed=seed)
+    sd = T.seeded(lambda: X3D(cfg.MODEL.X3D.PATH_CFG), seed).state_dict()
+    assert T.sd_checksum(sd) == int(g["x3dl_crc"])
+    tr = {}
+    with torch.no_grad():
+        R.x3d_forward(sd, clips, trace=tr)
+    assert _unit_check(g, "x3dl", tr) == 1
+    sd = T.seeded(lambda: SlowFast(cfg.MODEL.SLOWFAST.PATH_CFG), seed).state_dict()
+    assert T.sd_checksum(sd) == int(g["slowfast_crc"])
+    tr = {}
+    with torch.no_grad():
+        R.slowfast_forward(sd, R.pack_clips("slowfast4x16", clips), trace=tr)
+    tr["s1_fuse.1"] = tr["s1.1"]          # FuseFastToSlow returns [fused slow, untouched fast]
+    assert _unit_check(g, "slowfast", tr) == 10
+    sd = T.seeded(lambda: MViT(cfg.MODEL.MVIT2.PATH_CFG), seed).state_dict()
+    assert T.sd_checksum(sd) == int(g["mvit_crc"])
+    tr = {}
+    with torch.no_grad():
+        R.mvit_forward(sd, clips224, R.MVIT_S_ARCH, trace=tr)
+    assert _unit_check(g, "mvit", tr) == 16
+    sd = T.seeded(lambda: SwinTransformer3D(depths=[2, 2, 6, 2]), seed).state_dict()
+    assert T.sd_checksum(sd) == int(g["swin_crc"])
+    tr = {}
+    with torch.no_grad():
+        R.swin_forward(sd, clips224, trace=tr)
+    assert _unit_check(g, "swin", tr) == 15
