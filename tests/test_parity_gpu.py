@@ -182,6 +182,47 @@ def test_unit_level_outputs_vs_reference_hooks(dev, golden_dir):
     assert (out.cpu() - torch.as_tensor(g["out"])).abs().max().item() < MAP_TOL
 
 
+def _unit_err(g, tag, i, t):
+    sub = {k[len(tag) + 1:]: g[k] for k in g.files if k.startswith("%s_v%d_" % (tag, i + 1))}
+    shape = tuple(int(v) for v in sub["v%d_shape" % (i + 1)])
+    return T.feature_error(t.reshape(shape), sub, "v%d" % (i + 1))
+
+
+def test_backbone_units_vs_reference_hooks(dev, golden_dir):
+    """HIP block-by-block against what forward hooks on the reference's sub-modules recorded: the X3D stem,
+    every MViTv2-S block (seven distinct pooling / width cases), every Video-Swin-T block and PatchMerging output."""
+    from mspi_amd import engine as E
+    from mspi_amd.backbones.MViT import MViT
+    from mspi_amd.backbones.X3D import X3D
+    from mspi_amd.backbones.video_swin_transformer import SwinTransformer3D
+    from mspi_amd.config import cfg
+    g = _g(golden_dir, "backbone_units")
+    seed = int(g["seed"])
+    clips, _ = T.synth_inputs(2, 16, 64, 64, seed=seed, device=dev)
+    clips224, _ = T.synth_inputs(1, 16, 224, 224, seed=seed, device=dev)
+    m = T.seeded(lambda: X3D(cfg.MODEL.X3D.PATH_CFG), seed).to(dev)
+    assert _unit_err(g, "x3dl", 0, m.s1.run([clips])[0].as_ncdhw(24)) < 1e-4
+    m = T.seeded(lambda: MViT(cfg.MODEL.MVIT2.PATH_CFG), seed).to(dev)
+    keys = [str(k) for k in g["mvit_keys"]]
+    y = E.conv(clips224, m.pk)
+    for i, blk in enumerate(m.blocks):
+        y = blk.run(y)
+        assert keys[i] == "blocks.%d" % i
+        assert _unit_err(g, "mvit", i, y.as_rows().view(1, -1, y.C)) < 1e-4, keys[i]
+    m = T.seeded(lambda: SwinTransformer3D(depths=[2, 2, 6, 2]), seed).to(dev)
+    keys = [str(k) for k in g["swin_keys"]]
+    y = E.conv(clips224, m.pk)
+    for li, layer in enumerate(m.layers):
+        for bi, blk in enumerate(layer.blocks):
+            y = blk.run(y)
+            i = keys.index("layers.%d.blocks.%d" % (li, bi))
+            assert _unit_err(g, "swin", i, y.buf.view(1, y.T, y.H, y.W, y.C)) < 1e-4, keys[i]
+        if layer.downsample is not None:
+            y = layer.downsample.run(y)
+            i = keys.index("layers.%d.downsample" % li)
+            assert _unit_err(g, "swin", i, y.buf.view(1, y.T, y.H, y.W, y.C)) < 1e-4, keys[i]
+
+
 def test_stagewise_vs_oracle(dev):
     """Every stage boundary of the x3dl+audio model against the oracle on identical inputs (host CPU)."""
     from mspi_amd import engine as E
