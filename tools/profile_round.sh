@@ -19,5 +19,7 @@ rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o r --output-format csv -- python3
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o r --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-graph --tune-cache $CACHE --no-cpu-baseline --no-roofline > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 echo "write done"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_mfma -o r --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-graph --tune-cache $CACHE --no-cpu-baseline --no-roofline > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err
+echo "mfma done"
 # keep only the small summaries (the raw traces are tens of MB)
 find $OUT -name "*_kernel_trace.csv" -delete
