@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmspi_hip.so")
+LIB_PATH = os.environ.get("MSPI_LIB_PATH") or os.path.join(_HERE, "csrc", "libmspi_hip.so")   # override: A/B builds of the library
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_SWISH = range(5)
 PREC_F32, PREC_F16X3 = 0, 1
