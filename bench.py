@@ -25,7 +25,8 @@ if ROOT not in sys.path:
 # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order.  Two graphs in flight x three
 # branch streams each overlap best when every one of them has its own queue: measured on the bench line, same box,
 # 4 queues 570 / 6 queues 595-601 / 8 queues 559 clips/s (and +2.8 % on mvitv2s).  With a process group RCCL's own
-# streams take queues too and the picture flips (4: 567, 5: 571, 6: 498, 7: 427), so only the single-process run sets it.
+# streams take queues too and the picture flips (4: 567, 5: 571, 6: 498, 7: 427; high-priority RCCL streams or touching the
+# pool streams before RCCL starts do not repair it reliably), so only the single-process run sets it.
 # Must happen before the HIP runtime initialises, i.e. before torch is imported; an explicit setting wins.
 if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("MSPI_BENCH_FORCE_DIST"):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
