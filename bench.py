@@ -22,13 +22,68 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU (BASELINE configs[1]: 8)")
+    ap.add_argument("--model", default="x3dl", help="motion encoder: x3dl (configs[1], the bench line), slowfast4x16, mvitv2s, "
+                    "videoswins (the reference default, Swin-S), videoswint (configs[4]: the same class with depths 2,2,6,2), "
+                    "s3d, uniformerb, morphmlps")
+    ap.add_argument("--swin-depths", type=int, nargs=4, default=None, help="Video-Swin stage depths (overrides --model's)")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--wa", type=int, default=300, help="spectrogram columns (BASELINE: 300; reference default 111)")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--inflight", type=int, default=2, help="hipGraphs of the forward kept in flight (mspi_amd.runtime.GraphPipeline): "
+                    "consecutive steps (batches) replay round-robin on this many streams, so the low-occupancy tail of one batch "
+                    "overlaps the head of the next (each step is still one full forward of one batch; 1 = one batch at a time)")
+    ap.add_argument("--stream-layouts", type=int, default=4, help="stream layouts tried for the in-flight graphs during the untimed "
+                    "set-up (which streams share a hardware queue decides how well two batches overlap); 1 = take the first")
+    ap.add_argument("--no-autotune", action="store_true", help="keep the library's tile heuristic (default: time the "
+                    "kernel instantiations per conv shape during the first, untimed forward -- cudnn.benchmark's role upstream)")
+    ap.add_argument("--tune-cache", default=None, help="JSON file of tile choices: loaded when it exists (no tuning launches, "
+                    "e.g. under rocprofv3), otherwise written after the first forward")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1: nccl (= RCCL over xGMI); gloo only "
+                    "to rehearse the multi-rank control flow on a box where the ranks have to share one GPU")
+    ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / barrier / max-over-ranks timing / JSON line with "
+                    "NO GPU work (CPU test of the --gpus N launch path; the line says dry_run and carries no throughput)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-postproc", action="store_true", help="skip the second timed pass with the post-process kernel in the graph")
+    ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel timing table to stderr")
+    ap.add_argument("--kernel-detail", type=int, default=0, help="also print the N slowest individual launches")
+    return ap.parse_args()
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, as FRESH child
+    processes of this one -- which has not imported torch or touched the GPU yet, and never exec()s -- and hand back the
+    launcher's exit code.  Rank 0's JSON line goes straight to our stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+ARGS = parse() if __name__ == "__main__" else None
+if ARGS is not None and ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    sys.exit(launch_ranks(ARGS.gpus))
+
 # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order.  Two graphs in flight x three
 # branch streams each overlap best when every one of them has its own queue: measured on the bench line, same box,
 # 4 queues 570 / 6 queues 595-601 / 8 queues 559 clips/s (and +2.8 % on mvitv2s).  With a process group RCCL's own
 # streams take queues too and the picture flips (4: 567, 5: 571, 6: 498, 7: 427; high-priority RCCL streams or touching the
 # pool streams before RCCL starts do not repair it reliably), so only the single-process run sets it.
 # Must happen before the HIP runtime initialises, i.e. before torch is imported; an explicit setting wins.
-if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("MSPI_BENCH_FORCE_DIST"):
+if ARGS is not None and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("MSPI_BENCH_FORCE_DIST"):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
 
 import torch  # noqa: E402
@@ -39,52 +94,76 @@ F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
 
 
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8, help="clips per GPU (BASELINE configs[1]: 8)")
-    ap.add_argument("--model", default="x3dl")
-    ap.add_argument("--size", type=int, default=224)
-    ap.add_argument("--wa", type=int, default=300, help="spectrogram columns (BASELINE: 300; reference default 111)")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--inflight", type=int, default=2, help="hipGraphs of the forward kept in flight: consecutive steps (batches) "
-                    "replay round-robin on this many streams, so the low-occupancy tail of one batch overlaps the head of the "
-                    "next (each step is still one full forward of one batch; 1 = strictly one batch at a time)")
-    ap.add_argument("--stream-layouts", type=int, default=4, help="stream layouts tried for the in-flight graphs during the untimed "
-                    "set-up (which streams share a hardware queue decides how well two batches overlap); 1 = take the first")
-    ap.add_argument("--no-autotune", action="store_true", help="keep the library's tile heuristic (default: time the "
-                    "kernel instantiations per conv shape during the first, untimed forward -- cudnn.benchmark's role upstream)")
-    ap.add_argument("--tune-cache", default=None, help="JSON file of tile choices: loaded when it exists (no tuning launches, "
-                    "e.g. under rocprofv3), otherwise written after the first forward")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1: nccl (= RCCL over xGMI); gloo only "
-                    "to rehearse the multi-rank control flow on a box where the ranks have to share one GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel timing table to stderr")
-    ap.add_argument("--kernel-detail", type=int, default=0, help="also print the N slowest individual launches")
-    return ap.parse_args()
+def host_cores():
+    """CPU cores this process may actually use: physical cores (unique (package, core id) pairs of /proc/cpuinfo) limited
+    by the affinity mask and the cgroup CPU quota -- a GPU box hands a one-GPU job a share of the host, and a thread pool
+    sized by the machine's 128 logical CPUs then oversubscribes that share several times over."""
+    logical = len(os.sched_getaffinity(0))
+    phys = set()
+    try:
+        pkg = core = None
+        allowed = os.sched_getaffinity(0)
+        cpu = None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k = k.strip()
+            if k == "processor":
+                cpu = int(v)
+            elif k == "physical id":
+                pkg = int(v)
+            elif k == "core id":
+                core = int(v)
+            elif not k and cpu is not None:
+                if cpu in allowed and pkg is not None and core is not None:
+                    phys.add((pkg, core))
+                pkg = core = cpu = None
+    except (OSError, ValueError):
+        pass
+    n = len(phys) or logical
+    try:                                           # cgroup v2 quota: "max 100000" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, logical))
 
 
-def cpu_baseline(sd, cfg, name, clips, audio, budget_s=float(os.environ.get("MSPI_BENCH_CPU_BUDGET_S", "25"))):
-    """The oracle (CPU restatement pinned to the reference) on the host cores of this box: B=1 clips,
-    repeated until ~budget_s of CPU work.  A reported baseline, not the target."""
+def cpu_baseline(sd, cfg, name, clips, audio, budget_s=float(os.environ.get("MSPI_BENCH_CPU_BUDGET_S", "60"))):
+    """The oracle (CPU restatement pinned to the reference) on the host cores of this box, SURVEY 8d: torch threads = the
+    physical cores this job may use, batch 1 AND the bench batch, median of >= 5 forwards each (3 when one forward of the
+    full batch alone would take more than a fifth of the budget).  A reported baseline, not the target."""
     from oracle import restate as R
-    n = 0
-    t0 = time.time()
-    with torch.no_grad():
-        while True:
-            R.audio_visual_forward(sd, clips[n % clips.shape[0]:n % clips.shape[0] + 1],
-                                   audio[n % audio.shape[0]:n % audio.shape[0] + 1], name,
-                                   cfg.MODEL.LATERAL_BOOL, cfg.MODEL.LATERAL_STRIDE)
-            n += 1
-            el = time.time() - t0
-            if el > budget_s or (n >= 3 and el > 0.6 * budget_s):
-                break
-    return {"value": round(n / el, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d single-clip forwards of the same workload (B=1) through oracle/restate.py, torch %s CPU fp32"
-                      % (n, torch.__version__)}
+    cores = host_cores()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+
+    def run(b, n):
+        ts = []
+        with torch.no_grad():
+            for i in range(n + 1):                 # first forward untimed (thread pool, allocator)
+                t0 = time.time()
+                R.audio_visual_forward(sd, clips[:b], audio[:b], name, cfg.MODEL.LATERAL_BOOL, cfg.MODEL.LATERAL_STRIDE)
+                if i:
+                    ts.append(time.time() - t0)
+                elif b > 1 and time.time() - t0 > budget_s / 5:
+                    n = min(n, 3)
+                if len(ts) >= n:
+                    break
+        ts.sort()
+        return ts[len(ts) // 2], len(ts)
+
+    try:
+        t1, n1 = run(1, 5)
+        B = clips.shape[0]
+        tb, nb = run(B, 5) if B > 1 else (t1, n1)
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": round(B / tb, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+            "value_b1": round(1.0 / t1, 4), "batch": B,
+            "sample": "oracle/restate.py (torch %s CPU fp32, %d threads = physical cores available to the job) on the same workload: "
+                      "median of %d forwards at batch %d (`value`), median of %d at batch 1 (`value_b1`)"
+                      % (torch.__version__, cores, nb, B, n1)}
 
 
 def pmc_traffic(kname, model, B, S, wa):
@@ -104,16 +183,46 @@ def pmc_traffic(kname, model, B, S, wa):
     return {}
 
 
+def dry_run(args, rank, world):
+    """The launch contract without a GPU: rendezvous, barrier, K empty steps, max over ranks, one JSON line."""
+    multi = world > 1
+    if multi:
+        dist.init_process_group("gloo" if args.backend != "nccl" or not torch.cuda.is_available() else "nccl")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3)
+    if multi:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank == 0:
+        print(json.dumps({"metric": "clips_per_sec", "value": None, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dry_run": True, "data": "none",
+                          "config": {"workload": "dry run of the launch path: no GPU work", "global_batch": world * args.batch}}))
+    if multi:
+        dist.destroy_process_group()
+
+
+MODEL_ALIASES = {"videoswint": ("videoswins", [2, 2, 6, 2])}
+
+
 def main():
-    args = parse()
+    args = ARGS
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     # MSPI_BENCH_FORCE_DIST=1 under torch.distributed.run with ONE rank takes the whole multi-rank path (process group,
     # weight broadcast, per-step gather, barriers) -- the only way to exercise the RCCL calls on a one-GPU box
     multi = world > 1 or bool(os.environ.get("MSPI_BENCH_FORCE_DIST"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if os.environ.get("MSPI_BENCH_SHARE_GPU"):     # rehearsal of the N>1 control flow on a one-GPU box
@@ -129,10 +238,15 @@ def main():
     from mspi_amd import engine as E
     from mspi_amd import testing as T
     from mspi_amd.model.model_utils import AudioVisualSaliencyModel
+    from mspi_amd.runtime import GraphPipeline
 
-    name, B, S = args.model, args.batch, args.size
+    label, B, S = args.model, args.batch, args.size
+    name, depths = MODEL_ALIASES.get(label, (label, None))
+    depths = args.swin_depths or depths
     t_tok = {"x3dl": 16, "slowfast4x16": 4, "s3d": 4}.get(name, 8)
-    cfg = T.make_cfg(name, num_aud_tokens=9 * ((args.wa + 31) // 32), num_vis_tokens=t_tok * (S // 32) ** 2)
+    cfg = T.make_cfg(name, num_aud_tokens=9 * ((args.wa + 31) // 32), num_vis_tokens=t_tok * (S // 32) ** 2, swin_depths=depths)
+    if name == "videoswins":
+        label = "videoswin depths %s" % (list(cfg.MODEL.SWIN.DEPTHS),)
     devnull = open(os.devnull, "w")
     so, sys.stdout = sys.stdout, devnull          # the constructors print; keep stdout to the one JSON line
     try:
@@ -157,72 +271,29 @@ def main():
     if args.tune_cache and not have_cache and rank == 0:
         E.save_autotune(args.tune_cache)
     torch.cuda.synchronize()
-    graphs, outs, streams = [], [out], []
 
-    def capture_set(skip):
-        """`inflight` graphs of the forward, each captured on its own stream.  `skip` streams are drawn from torch's pool
-        first: which HARDWARE queue a HIP stream lands on follows creation order (GPU_MAX_HW_QUEUES round-robin), and two
-        batches only overlap when their streams do not share a queue -- the layout is therefore tuned like a conv tile."""
-        held = [torch.cuda.Stream() for _ in range(skip)]
-        gs, os_, ss = [], [], []
-        for _ in range(max(1, args.inflight)):
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                model(clips, audio)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            # thread_local: the capture must not trip over CUDA calls of other threads (the RCCL watchdog polls events)
-            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                o, _ = model(clips, audio)
-            gs.append(g)
-            os_.append(o)
-            ss.append(side)
-        return gs, os_, ss, held
+    def log(msg):
+        if rank == 0:
+            sys.stderr.write(msg + "\n")
 
-    def replay_rate(gs, ss, n=8):
-        for i in range(2):
-            with torch.cuda.stream(ss[i % len(gs)]):
-                gs[i % len(gs)].replay()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(n):
-            with torch.cuda.stream(ss[i % len(gs)]):
-                gs[i % len(gs)].replay()
-        torch.cuda.synchronize()
-        return n / (time.perf_counter() - t1)
-
-    layout = None
-    if not args.no_graph:
-        trials = args.stream_layouts if args.inflight > 1 else 1
-        best = None
-        for skip in range(max(1, trials)):
-            cand = capture_set(skip)
-            rate = replay_rate(cand[0], cand[2]) if trials > 1 else 0.0
-            if trials > 1 and rank == 0:
-                sys.stderr.write("[bench] stream layout %d: %.1f batches/s\n" % (skip, rate))
-            if best is None or rate > best[0]:
-                best, layout = (rate, cand), skip
-            del cand
-        graphs, outs, streams, _held = best[1]
-        del best
-        torch.cuda.empty_cache()
-    depth = max(1, len(graphs))
+    pipe = None
+    if not args.no_graph:       # the product's launch path: mspi_amd/runtime.py
+        pipe = GraphPipeline(lambda c, a: model(c, a)[0], (clips, audio), depth=args.inflight,
+                             layouts=args.stream_layouts, log=log)
+    depth = pipe.depth if pipe else 1
+    outs = [s.outs[0] for s in pipe.slots] if pipe else [out]
     collecting = multi or bool(os.environ.get("MSPI_BENCH_FAKE_COLLECT"))     # FAKE: the stream/event choreography without dist
-    counter = [0]
     # Map collection (graph mode).  Each replay is followed, ON ITS OWN STREAM, by a copy of its maps into one of NSLOT
-    # staging buffers and an event record; the gather runs on a separate non-blocking stream behind that event.  Nothing
-    # ever makes a graph's stream wait on another stream: a cross-stream wait in front of a replay keeps the runtime from
-    # queueing that graph behind the running one (measured 583 -> 531 clips/s), and torch's default stream is HIP's NULL
-    # stream, where any operation is an implicit barrier against the blocking streams a hipGraph runs its branches on.
-    # Re-use of a staging slot (NSLOT steps later) is guarded on the HOST: the gather that last read it must have finished.
+    # staging buffers and an event record (GraphPipeline.after); the gather runs on a separate non-blocking stream behind
+    # that event.  Nothing ever makes a graph's stream wait on another stream, and nothing runs on torch's default stream
+    # (runtime.py).  Re-use of a staging slot (NSLOT steps later) is guarded on the HOST.
     NSLOT = 4
-    stage = [torch.empty_like(outs[0]) for _ in range(NSLOT)] if (graphs and collecting) else []
+    stage = [torch.empty_like(outs[0]) for _ in range(NSLOT)] if (pipe and collecting) else []
     done = [torch.cuda.Event() for _ in range(NSLOT)]
     collected = [None] * NSLOT
     pending = [None]                              # staging slot whose maps still have to be collected
-    comm_stream = torch.cuda.Stream() if graphs else torch.cuda.current_stream()
+    comm_stream = torch.cuda.Stream() if pipe else torch.cuda.current_stream()
+    counter = [0]
 
     def gather(o):
         if not multi or os.environ.get("MSPI_BENCH_NO_GATHER"):     # experiment switches: everything but the collective
@@ -244,63 +315,83 @@ def main():
             collect(pending[0])
             pending[0] = None
 
+    def stage_maps(k, o):                         # runs on the replay's own stream, right behind it
+        slot = (counter[0] - 1) % NSLOT
+        stage[slot].copy_(o[0])
+        done[slot].record()
+
+    if pipe and collecting:
+        pipe.after = stage_maps
+
     def step():
         i = counter[0]
         counter[0] += 1
-        if not graphs:
+        if not pipe:
             o, _ = model(clips, audio)
             outs[0] = o
             gather(o)
-            return o
-        k = i % depth
+            return
         if not collecting:
-            with torch.cuda.stream(streams[k]):
-                graphs[k].replay()
-            return outs[k]
+            pipe.submit()
+            return
         slot = i % NSLOT
         if collected[slot] is not None and not collected[slot].query():
             collected[slot].synchronize()         # host-side guard; with 4 slots it never actually waits
-        with torch.cuda.stream(streams[k]):
-            graphs[k].replay()
-            stage[slot].copy_(outs[k])
-            done[slot].record()
+        pipe.submit()
         # the gather of the PREVIOUS batch is issued after this batch's replay is queued, so a collective that blocks the
         # host cannot drain the GPU between batches
         prev, pending[0] = pending[0], slot
         if prev is not None:
             collect(prev)
-        return outs[k]
 
-    for _ in range(args.warmup):
-        step()
-    flush()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ta = time.perf_counter()
-    flush()                                       # the last batch's maps: K replays and K gathers inside the timed region
-    torch.cuda.synchronize()
-    tb = time.perf_counter()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if os.environ.get("MSPI_BENCH_DEBUG") and rank == 0:
-        sys.stderr.write("[bench] enqueue %.1f ms, drain %.1f ms, barrier %.1f ms\n" % (
-            1e3 * (ta - t0), 1e3 * (tb - ta), 1e3 * (t0 + elapsed - tb)))
-    if multi:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    def timed(step_fn, flush_fn):
+        for _ in range(args.warmup):
+            step_fn()
+        flush_fn()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn()
+        ta = time.perf_counter()
+        flush_fn()                                # the last batch's maps: K replays and K gathers inside the timed region
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if os.environ.get("MSPI_BENCH_DEBUG") and rank == 0:
+            sys.stderr.write("[bench] enqueue %.1f ms, drain %.1f ms, barrier %.1f ms\n" % (
+                1e3 * (ta - t0), 1e3 * (tb - ta), 1e3 * (t0 + el - tb)))
+        if multi:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        return el
+
+    elapsed = timed(step, flush)
 
     ok = all(bool(torch.isfinite(o).all().item()) and abs(torch.logsumexp(o.flatten(1), 1)).max().item() < 1e-3 for o in outs)
     if depth > 1:                                 # every graph in flight computed the same maps
         ok = ok and all(torch.equal(outs[0], o) for o in outs[1:])
     if not ok:
         raise SystemExit("bench: the saliency maps are not finite log-probability maps")
+
+    # SURVEY 8d metric (2): saliency-map ms/clip INCLUDING the post-process kernels (inference.py:72-91: blur, exp, resize to
+    # 640x480, min-max, uint8) -- the same pipeline with mspi_postprocess_u8 captured behind the forward, timed the same way.
+    pp = None
+    if pipe and not args.no_postproc:
+        pipe_pp = GraphPipeline(lambda c, a: E.postprocess_u8(model(c, a)[0], (480, 640)), (clips, audio), depth=args.inflight,
+                                layouts=1)
+        el_pp = timed(pipe_pp.submit, lambda: None)
+        u8 = pipe_pp.fetch(0)
+        if not (u8.dtype == torch.uint8 and tuple(u8.shape) == (B, 480, 640) and int(u8.max()) == 255 and int(u8.min()) == 0):
+            raise SystemExit("bench: post-processed maps are not min-max normalised uint8 images")
+        pp = {"ms_per_clip_with_postproc": round(1e3 * el_pp / args.steps / B, 4),
+              "latency_ms_per_batch_with_postproc": round(pipe_pp.latency_ms(), 4)}
+        del pipe_pp, u8
 
     if rank != 0:
         if multi:
@@ -316,24 +407,19 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s motion encoder + ConvNeXt-T + ResNet18 audio + SyncBlock + decoder (AudioVisualSaliencyModel "
                                "forward), batch %d/GPU, clips 3x16x%dx%d, spectrogram 1x257x%d, inputs resident in HBM"
-                               % (name, B, S, S, args.wa),
+                               % (label, B, S, S, args.wa),
                    "global_batch": world * B,
-                   "launch": "eager" if not graphs else "hipGraph replay, %d batch%s in flight" % (depth, "es" if depth > 1 else ""),
-                   "stream_layout": layout,
+                   "launch": "eager" if not pipe else "hipGraph replay (mspi_amd.runtime.GraphPipeline), %d batch%s in flight"
+                             % (depth, "es" if depth > 1 else ""),
+                   "stream_layout": pipe.layout if pipe else None,
                    "parallelism": "clip-sharded x%d (weights broadcast once, maps gathered per step over RCCL)" % world
                    if multi else "single GPU"},
     }
-
-    if graphs:       # latency of ONE batch alone on the chip (no neighbouring batch in flight): median of 7 replays
-        lat = []
-        for _ in range(7):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            with torch.cuda.stream(streams[0]):
-                graphs[0].replay()
-            torch.cuda.synchronize()
-            lat.append(time.perf_counter() - t1)
-        line["latency_ms_per_batch"] = round(1e3 * sorted(lat)[len(lat) // 2], 4)
+    if pp:
+        line.update(pp)
+    if pipe:         # latency of ONE batch alone on the chip (no neighbouring batch in flight): median of 7 replays
+        line["latency_ms_per_batch"] = round(pipe.latency_ms(), 4)
+        line["saliency_map_ms_per_clip"] = round((pp["latency_ms_per_batch_with_postproc"] if pp else line["latency_ms_per_batch"]) / B, 4)
 
     if not args.no_roofline:
         # per-launch HIP-event timing of every C-ABI call: eager, same inputs, ONE stream (the branch overlap is
@@ -384,7 +470,7 @@ def main():
             line["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                                 "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"])}
-        line["roofline"].update(pmc_traffic(kname, name, B, S, args.wa))
+        line["roofline"].update(pmc_traffic(kname, args.model, B, S, args.wa))
         line["roofline"]["launches_per_step"] = d["calls"] // 3
         line["roofline"]["avg_launch_us"] = round(1e3 * d["ms"] / d["calls"], 3)
         line["roofline"]["share_of_step"] = round(d["ms"] / tot, 4)

@@ -1,0 +1,148 @@
+"""hipGraph replay with several batches in flight -- the launch side of the hot path.
+
+A forward of the saliency model is ~430 kernel launches of 10-130 us on three HIP streams; launched eagerly from Python
+the chip idles between them.  `GraphPipeline` captures the forward for ONE input shape into `depth` hipGraphs (each with
+its own static input / output buffers and its own stream) and replays them round-robin, so the low-occupancy stretches
+of one batch (X3D's 20 us kernels, the decoder tail) overlap the GEMM-heavy stretches of the next.  Every replay is still
+one full forward of one batch.  The reference launches eagerly through ATen with `cudnn.benchmark` (inference.py:19); this
+module is what replaces that launch path, for `bench.py` and for the clip loop of `mspi_amd.inference` alike.
+
+Rules the implementation keeps (each measured, DESIGN.md section 3 "Scheduling"):
+  * nothing is ever queued on torch's default stream (HIP's NULL stream: any operation there is an implicit barrier
+    against the blocking streams a hipGraph runs its parallel branches on);
+  * a graph's stream never waits on another graph's stream; the only cross-stream wait is on the PRODUCER of fresh
+    inputs (`submit(*inputs)`), and the resident-input form `submit()` has none;
+  * which hardware queue a stream lands on follows creation order, so `layouts` > 1 tries a few creation orders during
+    the untimed set-up and keeps the fastest (two graphs x three branch streams overlap best on distinct queues).
+"""
+import time
+
+import torch
+
+
+class _Slot:
+    __slots__ = ("stream", "graph", "inputs", "outs", "done", "busy")
+
+
+class GraphPipeline:
+    """`fn(*inputs)` -> tensor | tuple of tensors, captured for the shapes of `example_inputs` (device tensors).
+
+    submit(*inputs) -> ticket     copy `inputs` into the next slot's static buffers (stream-ordered behind their producer on
+                                   the current stream) and replay its graph; with no arguments the slot's resident inputs
+                                   (the example, or whatever was last submitted) are used and no cross-stream wait exists
+    fetch(ticket)   -> outputs    wait for that replay; the tensors are the slot's static outputs, valid until the slot
+                                   is submitted again (`depth` submits later)
+    """
+
+    def __init__(self, fn, example_inputs, depth=2, layouts=1, log=None, capture_error_mode="thread_local"):
+        self.fn, self.depth = fn, max(1, int(depth))
+        self.example = tuple(example_inputs)
+        if not all(torch.is_tensor(t) and t.is_cuda for t in self.example):
+            raise ValueError("GraphPipeline needs device-resident example inputs (there is no CPU path)")
+        self._mode = capture_error_mode
+        self._count = 0
+        self.layout = None
+        self.after = None       # optional callable(slot_index, outs), run on the slot's stream right behind each replay
+        trials = max(1, int(layouts)) if self.depth > 1 else 1
+        best = None
+        for skip in range(trials):
+            held = [torch.cuda.Stream() for _ in range(skip)]      # shifts the creation order = the hardware-queue mapping
+            slots = [self._capture() for _ in range(self.depth)]
+            rate = self._rate(slots) if trials > 1 else 0.0
+            if log is not None and trials > 1:
+                log("[runtime] stream layout %d: %.1f batches/s" % (skip, rate))
+            if best is None or rate > best[0]:
+                best, self.layout = (rate, slots, held), skip
+            del slots, held
+        self.slots, self._held = best[1], best[2]
+        del best
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ set-up
+    def _capture(self):
+        s = _Slot()
+        s.stream = torch.cuda.Stream()
+        s.inputs = tuple(t.clone() for t in self.example)
+        s.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s.stream):
+            self.fn(*s.inputs)                                     # warms this stream's allocator pools
+        torch.cuda.current_stream().wait_stream(s.stream)
+        torch.cuda.synchronize()
+        s.graph = torch.cuda.CUDAGraph()
+        # thread_local: the capture must not trip over HIP calls of other threads (the RCCL watchdog polls events)
+        with torch.cuda.graph(s.graph, stream=s.stream, capture_error_mode=self._mode):
+            out = self.fn(*s.inputs)
+        s.outs = out if isinstance(out, (tuple, list)) else (out,)
+        s.done = torch.cuda.Event()
+        s.busy = False
+        return s
+
+    @staticmethod
+    def _rate(slots, n=8):
+        def go(i):
+            s = slots[i % len(slots)]
+            with torch.cuda.stream(s.stream):
+                s.graph.replay()
+        for i in range(2):
+            go(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            go(i)
+        torch.cuda.synchronize()
+        return n / (time.perf_counter() - t0)
+
+    # ------------------------------------------------------------------ steady state
+    def submit(self, *inputs):
+        k = self._count % self.depth
+        self._count += 1
+        s = self.slots[k]
+        if inputs:
+            if len(inputs) != len(s.inputs):
+                raise ValueError("submit() takes %d tensors" % len(s.inputs))
+            for t, dst in zip(inputs, s.inputs):
+                if tuple(t.shape) != tuple(dst.shape):
+                    raise ValueError("graph captured for %s, got %s" % (tuple(dst.shape), tuple(t.shape)))
+            produced = torch.cuda.Event()
+            produced.record()                                      # on the producer's (current) stream
+            with torch.cuda.stream(s.stream):
+                s.stream.wait_event(produced)
+                for t, dst in zip(inputs, s.inputs):
+                    dst.copy_(t, non_blocking=True)
+                    t.record_stream(s.stream)
+                s.graph.replay()
+                if self.after is not None:
+                    self.after(k, s.outs)
+                s.done.record()
+        else:
+            with torch.cuda.stream(s.stream):
+                s.graph.replay()
+                if self.after is not None:
+                    self.after(k, s.outs)
+                s.done.record()
+        s.busy = True
+        return k
+
+    def fetch(self, ticket):
+        s = self.slots[ticket]
+        if s.busy:
+            s.done.synchronize()
+            s.busy = False
+        return s.outs if len(s.outs) > 1 else s.outs[0]
+
+    def drain(self):
+        for k in range(self.depth):
+            self.fetch(k)
+
+    def latency_ms(self, n=7):
+        """One batch alone on the chip (nothing else in flight): median of n replays, host-timed."""
+        lat = []
+        s = self.slots[0]
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(s.stream):
+                s.graph.replay()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        return 1e3 * sorted(lat)[len(lat) // 2]

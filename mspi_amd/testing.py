@@ -71,6 +71,18 @@ def make_cfg(name, num_aud_tokens=36, num_vis_tokens=None, swin_depths=None):
     return c
 
 
+def golden_hw(g):
+    """Frame size of a model-level fixture (older fixtures are square and only carry `size`)."""
+    return (int(g["H"]), int(g["W"])) if "H" in g.files else (int(g["size"]), int(g["size"]))
+
+
+def golden_cfg(g, name):
+    """The config a model-level fixture (oracle/gen_golden.py::_model_case) was generated with."""
+    depths = [int(v) for v in g["swin_depths"]] if "swin_depths" in g.files else []
+    return make_cfg(name, num_aud_tokens=int(g["num_aud_tokens"]), num_vis_tokens=int(g["num_vis_tokens"]),
+                    swin_depths=depths or None)
+
+
 def seeded(build, seed=0):
     """build() under torch.manual_seed(seed), then randomize_ (which re-draws everything), eval()."""
     torch.manual_seed(seed)

@@ -52,9 +52,11 @@ class _NoWeights(dict):
         return _NoWeights()
 
 
-def build_reference_model(name, cls_name, num_vis_tokens=None):
+def build_reference_model(name, cls_name, num_vis_tokens=None, swin_depths=None):
     """Construct the reference AudioVisualSaliencyModel / VisualSaliencyModel offline:
-    create_model -> stand-in, the three torch.load of absent weight files -> no-ops."""
+    create_model -> stand-in, the three torch.load of absent weight files -> no-ops.  `swin_depths`: the reference's
+    factory calls SwinTransformer3D() (= Swin-S, model/get_video_backbones.py:25); BASELINE configs[4] names Swin-T,
+    which is the SAME reference class with depths=[2,2,6,2] -- the factory's name is bound to a partial of it."""
     cfg = rh.with_config(name)
     if num_vis_tokens is not None:
         cfg.MODEL.NUM_VIS_TOKENS[name] = num_vis_tokens
@@ -66,6 +68,11 @@ def build_reference_model(name, cls_name, num_vis_tokens=None):
     real_load, real_lsd, real_sf_lw = torch.load, nn.Module.load_state_dict, ref_sf.SlowFast.load_weight
     real_s3d_lw = ref_s3d.S3D_features_only.load_weight
     real_morph_lw = ref_morph.MorphMLP_32_features_only.load_weight
+    import functools
+    import model.get_video_backbones as ref_factory
+    real_swin = ref_factory.SwinTransformer3D
+    if swin_depths is not None:
+        ref_factory.SwinTransformer3D = functools.partial(real_swin, depths=list(swin_depths))
     ref_morph.MorphMLP_32_features_only.load_weight = lambda self, path: None   # deletes head.* from the (absent) checkpoint
     ref_sf.SlowFast.load_weight = lambda self, path: None    # caffe2 .pkl loader opens the (absent) file itself
     ref_s3d.S3D_features_only.load_weight = lambda self, path: None   # raises on the absent file before any torch.load
@@ -77,6 +84,7 @@ def build_reference_model(name, cls_name, num_vis_tokens=None):
         torch.load, nn.Module.load_state_dict, ref_sf.SlowFast.load_weight = real_load, real_lsd, real_sf_lw
         ref_s3d.S3D_features_only.load_weight = real_s3d_lw
         ref_morph.MorphMLP_32_features_only.load_weight = real_morph_lw
+        ref_factory.SwinTransformer3D = real_swin
     return m.eval()
 
 
@@ -192,6 +200,24 @@ def case_mvit_backbone(size=224, seed=0):
     _save("mvit_backbone_%d" % size, seed=seed, size=size, batch=1, sd_crc=T.sd_checksum(sd), **_feat_fixture(feats))
 
 
+def case_mvit_backbone_224x384(seed=0):
+    """MViTv2-S backbone on the reference's default 224x384 frames (rel-pos table interpolation along W)."""
+    from mspi_amd.backbones.MViT import MViT
+    from mspi_amd.config import cfg as pcfg
+    prod = T.seeded(lambda: MViT(pcfg.MODEL.MVIT2.PATH_CFG), seed)
+    sd = prod.state_dict()
+    rcfg = rh.with_config("mvitv2s")
+    from backbones.MViT import MViT as RefMViT
+    ref = RefMViT(path_to_configs=rcfg.MODEL.MVIT2.PATH_CFG).eval()
+    ref.load_state_dict(sd, strict=True)
+    clips, _ = T.synth_inputs(1, 16, 224, 384, seed=seed)
+    with torch.no_grad():
+        feats = ref([clips])
+        ora = R.mvit_forward(sd, clips, R.MVIT_S_ARCH)
+    _check_restatement("mvit backbone 224x384", feats, ora, 5e-5)
+    _save("mvit_backbone_224x384", seed=seed, H=224, W=384, batch=1, sd_crc=T.sd_checksum(sd), **_feat_fixture(feats))
+
+
 def case_swin_backbone(seed=0):
     """Swin-T depths through the reference class keeps the CPU forward short; Swin-S differs only in
     the number of stage-2 blocks.  224x224 (no padding anywhere)."""
@@ -240,6 +266,23 @@ def case_av_mvit_224():
     _model_case("mvitv2s", "AudioVisualSaliencyModel", 224, 1, 111, 0, "av_mvit_224")
 
 
+def case_av_swin_t_224():
+    """BASELINE configs[4]: VideoSwin-T (reference class, depths=[2,2,6,2]) + audio at Wa=300, whole model."""
+    _model_case("videoswins", "AudioVisualSaliencyModel", 224, 1, 300, 0, "av_swin_t_224", swin_depths=[2, 2, 6, 2])
+
+
+def case_av_mvit_224_wa300():
+    """BASELINE configs[3]: MViTv2-S + audio with the 257x300 spectrogram (90 audio tokens)."""
+    _model_case("mvitv2s", "AudioVisualSaliencyModel", 224, 1, 300, 0, "av_mvit_224_wa300")
+
+
+def case_av_mvit_224x384():
+    """The reference's DEFAULT deployment shape (config.py:14,49,59): mvitv2s on 224x384 frames, Wa=111, 8*7*12 visual
+    tokens.  W=384 gives 96/48/24/12-wide token grids against rel_pos_w tables sized for 56/28/14/7: get_rel_pos's linear
+    interpolation (backbones/MViT.py:207-220) runs in every block."""
+    _model_case("mvitv2s", "AudioVisualSaliencyModel", (224, 384), 1, 111, 0, "av_mvit_224x384")
+
+
 def case_av_slowfast_64():
     _model_case("slowfast4x16", "AudioVisualSaliencyModel", 64, 2, 111, 0, "av_slowfast_64")
 
@@ -261,22 +304,24 @@ def case_resnet18_audio(seed=0):
         _save("resnet18_audio_%d" % wa, seed=seed, batch=2, sd_crc=T.sd_checksum(sd), out=out)
 
 
-def _model_case(name, cls_name, size, B, wa, seed, tag):
+def _model_case(name, cls_name, size, B, wa, seed, tag, swin_depths=None):
+    """`size`: frame edge, or (H, W) for rectangular frames (the reference default is 224x384, config.py:14)."""
     from mspi_amd.model import model_utils as pm
+    H, W = (size, size) if isinstance(size, int) else size
     t_tok = {"x3dl": 16, "slowfast4x16": 4, "s3d": 4}.get(name, 8)
-    nvt = t_tok * (size // 32) ** 2
+    nvt = t_tok * (H // 32) * (W // 32)
     aud_tok = 9 * ((wa + 31) // 32)
-    pcfg = T.make_cfg(name, num_aud_tokens=aud_tok, num_vis_tokens=nvt)
+    pcfg = T.make_cfg(name, num_aud_tokens=aud_tok, num_vis_tokens=nvt, swin_depths=swin_depths)
     prod = T.condition_(T.seeded(lambda: getattr(pm, cls_name)(pcfg), seed), name)
     sd = prod.state_dict()
-    ref = build_reference_model(name, cls_name, num_vis_tokens=nvt)
+    ref = build_reference_model(name, cls_name, num_vis_tokens=nvt, swin_depths=swin_depths)
     missing = set(ref.state_dict()) ^ set(sd)
     assert not missing, "state-dict keys differ: %s" % sorted(missing)[:8]
     ref.load_state_dict(sd, strict=True)
     if cls_name == "AudioVisualSaliencyModel" and aud_tok != 36:   # F3: rebuild the plain-tensor table
         import model.model_utils as mu
         ref.aud_vis_sync_block.aud_pos_embed = mu.get_sinusoid_encoding_table(aud_tok, 512)
-    clips, audio = T.synth_inputs(B, 16, size, size, Wa=wa, seed=seed)
+    clips, audio = T.synth_inputs(B, 16, H, W, Wa=wa, seed=seed)
     t0 = time.time()
     with torch.no_grad():
         if cls_name == "AudioVisualSaliencyModel":
@@ -289,7 +334,8 @@ def _model_case(name, cls_name, size, B, wa, seed, tag):
             loss = torch.zeros(())
     print("  reference forward %.1fs; logsumexp=%.2e" % (time.time() - t0, torch.logsumexp(out[0], (0, 1)).item()))
     _check_restatement(tag, [out], [o2], 5e-5)
-    _save(tag, seed=seed, size=size, batch=B, wa=wa, num_vis_tokens=nvt, num_aud_tokens=aud_tok,
+    _save(tag, seed=seed, size=H, H=H, W=W, batch=B, wa=wa, num_vis_tokens=nvt, num_aud_tokens=aud_tok,
+          swin_depths=np.array(swin_depths if swin_depths is not None else [], dtype=np.int64),
           sd_crc=T.sd_checksum(sd), out=out, loss=loss)
 
 

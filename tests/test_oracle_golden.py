@@ -125,6 +125,21 @@ def test_mvit_backbone(golden_dir):
         assert T.feature_error(f, g, "v%d" % (i + 1)) <= 1e-6
 
 
+def test_mvit_backbone_224x384(golden_dir):
+    """The reference's default frame size (config.py:14): rel_pos_w tables are interpolated (MViT.py:207-220)."""
+    from mspi_amd.backbones.MViT import MViT
+    from mspi_amd.config import cfg
+    g = _g(golden_dir, "mvit_backbone_224x384")
+    sd = T.seeded(lambda: MViT(cfg.MODEL.MVIT2.PATH_CFG), int(g["seed"])).state_dict()
+    assert T.sd_checksum(sd) == int(g["sd_crc"])
+    clips, _ = T.synth_inputs(1, 16, int(g["H"]), int(g["W"]), seed=int(g["seed"]))
+    with torch.no_grad():
+        feats = R.mvit_forward(sd, clips, R.MVIT_S_ARCH)
+    assert [tuple(f.shape[2:]) for f in feats] == [(8, 56, 96), (8, 28, 48), (8, 14, 24), (8, 7, 12)]
+    for i, f in enumerate(feats):
+        assert T.feature_error(f, g, "v%d" % (i + 1)) <= 1e-6
+
+
 def test_swin_backbone(golden_dir):
     from mspi_amd.backbones.video_swin_transformer import SwinTransformer3D
     g = _g(golden_dir, "swin_t_backbone_224")
@@ -189,18 +204,21 @@ def test_resnet18_audio(golden_dir, wa):
 
 def _model(g, name, cls):
     from mspi_amd.model import model_utils as pm
-    cfg = T.make_cfg(name, num_aud_tokens=int(g["num_aud_tokens"]), num_vis_tokens=int(g["num_vis_tokens"]))
+    cfg = T.golden_cfg(g, name)
     m = T.condition_(T.seeded(lambda: getattr(pm, cls)(cfg), int(g["seed"])), name)
     sd = m.state_dict()
     assert T.sd_checksum(sd) == int(g["sd_crc"]), "seeded weights drifted from the ones the golden was made with"
-    clips, audio = T.synth_inputs(int(g["batch"]), 16, int(g["size"]), int(g["size"]), Wa=int(g["wa"]), seed=int(g["seed"]))
+    H, W = T.golden_hw(g)
+    clips, audio = T.synth_inputs(int(g["batch"]), 16, H, W, Wa=int(g["wa"]), seed=int(g["seed"]))
     return cfg, sd, clips, audio
 
 
 @pytest.mark.parametrize("case,name", [("av_x3dl_64", "x3dl"), ("av_x3dl_224", "x3dl"), ("av_slowfast_64", "slowfast4x16"),
                                        ("av_mvit_224", "mvitv2s"), ("av_swin_s_224", "videoswins"), ("av_s3d_64", "s3d"),
                                        ("av_uniformer_64", "uniformerb"), ("av_morphmlp_224", "morphmlps"),
-                                       ("av_slowfast_224", "slowfast4x16"), ("av_uniformer_224", "uniformerb"), ("av_s3d_224", "s3d")])
+                                       ("av_slowfast_224", "slowfast4x16"), ("av_uniformer_224", "uniformerb"), ("av_s3d_224", "s3d"),
+                                       ("av_swin_t_224", "videoswins"), ("av_mvit_224_wa300", "mvitv2s"),
+                                       ("av_mvit_224x384", "mvitv2s")])
 def test_audio_visual_model(golden_dir, case, name):
     g = _g(golden_dir, case)
     cfg, sd, clips, audio = _model(g, name, "AudioVisualSaliencyModel")

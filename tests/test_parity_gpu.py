@@ -95,6 +95,18 @@ def test_mvit_backbone_vs_golden(dev, golden_dir):
         assert T.feature_error(f, g, "v%d" % (i + 1)) < 2e-4, "v%d" % (i + 1)
 
 
+def test_mvit_backbone_224x384_vs_golden(dev, golden_dir):
+    """Reference default frame size: every block interpolates its rel_pos_w table (MViT.py:207-220 -> MViT._rel_rows)."""
+    from mspi_amd.backbones.MViT import MViT
+    from mspi_amd.config import cfg
+    g = _g(golden_dir, "mvit_backbone_224x384")
+    m = T.seeded(lambda: MViT(cfg.MODEL.MVIT2.PATH_CFG), int(g["seed"])).to(dev)
+    clips, _ = T.synth_inputs(1, 16, int(g["H"]), int(g["W"]), seed=int(g["seed"]), device=dev)
+    feats = m([clips])
+    for i, f in enumerate(feats):
+        assert T.feature_error(f, g, "v%d" % (i + 1)) < 2e-4, "v%d" % (i + 1)
+
+
 def test_swin_backbone_vs_golden(dev, golden_dir):
     from mspi_amd.backbones.video_swin_transformer import SwinTransformer3D
     g = _g(golden_dir, "swin_t_backbone_224")
@@ -129,17 +141,20 @@ def test_resnet18_audio_vs_golden(dev, golden_dir, wa):
 
 def _build(g, name, cls, dev):
     from mspi_amd.model import model_utils as pm
-    cfg = T.make_cfg(name, num_aud_tokens=int(g["num_aud_tokens"]), num_vis_tokens=int(g["num_vis_tokens"]))
+    cfg = T.golden_cfg(g, name)
     m = T.condition_(T.seeded(lambda: getattr(pm, cls)(cfg), int(g["seed"])), name)
     assert T.sd_checksum(m.state_dict()) == int(g["sd_crc"])
-    clips, audio = T.synth_inputs(int(g["batch"]), 16, int(g["size"]), int(g["size"]), Wa=int(g["wa"]), seed=int(g["seed"]), device=dev)
+    H, W = T.golden_hw(g)
+    clips, audio = T.synth_inputs(int(g["batch"]), 16, H, W, Wa=int(g["wa"]), seed=int(g["seed"]), device=dev)
     return cfg, m.to(dev), clips, audio
 
 
 @pytest.mark.parametrize("case,name", [("av_x3dl_64", "x3dl"), ("av_x3dl_224", "x3dl"), ("av_slowfast_64", "slowfast4x16"),
                                        ("av_mvit_224", "mvitv2s"), ("av_swin_s_224", "videoswins"), ("av_s3d_64", "s3d"),
                                        ("av_uniformer_64", "uniformerb"), ("av_morphmlp_224", "morphmlps"),
-                                       ("av_slowfast_224", "slowfast4x16"), ("av_uniformer_224", "uniformerb"), ("av_s3d_224", "s3d")])
+                                       ("av_slowfast_224", "slowfast4x16"), ("av_uniformer_224", "uniformerb"), ("av_s3d_224", "s3d"),
+                                       ("av_swin_t_224", "videoswins"), ("av_mvit_224_wa300", "mvitv2s"),
+                                       ("av_mvit_224x384", "mvitv2s")])
 def test_audio_visual_model_vs_golden(dev, golden_dir, case, name):
     g = _g(golden_dir, case)
     cfg, m, clips, audio = _build(g, name, "AudioVisualSaliencyModel", dev)
@@ -147,7 +162,8 @@ def test_audio_visual_model_vs_golden(dev, golden_dir, case, name):
     assert tuple(out.shape) == g["out"].shape
     err = (out.cpu() - torch.as_tensor(g["out"])).abs().max().item()
     assert err < MAP_TOL, "max-abs map error %.3e" % err
-    assert abs(loss.item() - float(g["loss"])) < MAP_TOL
+    # relative: |loss| is 7e-4 .. 1e-2 on these fixtures, an absolute 1e-3 would accept a zero
+    assert abs(loss.item() - float(g["loss"])) < 1e-3 * max(abs(float(g["loss"])), 1e-2), (loss.item(), float(g["loss"]))
     lse = torch.logsumexp(out.flatten(1), 1).abs().max().item()
     assert lse < 1e-4, "output is not a log-probability map"
 
@@ -271,15 +287,19 @@ def test_sync_block_token_mismatch_raises(dev):
         m(clips, audio)
 
 
-def test_full_size_properties(dev):
-    """BASELINE shape (batch 8, 16x224x224 + 257x300): size-independent properties -- normalisation,
-    determinism, and independence of clips (a clip's map does not depend on its batch-mates)."""
+@pytest.mark.parametrize("name,B,depths", [("x3dl", 8, None), ("slowfast4x16", 16, None), ("mvitv2s", 8, None),
+                                           ("videoswins", 8, [2, 2, 6, 2])])
+def test_full_size_properties(dev, name, B, depths):
+    """BASELINE configs[1..4] at their per-GPU shapes (x3dl batch 8, slowfast batch 16, mvitv2s and videoswin-T batch 8;
+    16x224x224 + 257x300): size-independent properties -- normalisation, bitwise determinism, and independence of clips
+    (a clip's map does not depend on its batch-mates, which is what lets the batch shard over GPUs)."""
     from mspi_amd.model.model_utils import AudioVisualSaliencyModel
-    cfg = T.make_cfg("x3dl", num_aud_tokens=90)
+    t_tok = {"x3dl": 16, "slowfast4x16": 4}.get(name, 8)
+    cfg = T.make_cfg(name, num_aud_tokens=90, num_vis_tokens=t_tok * 49, swin_depths=depths)
     m = T.seeded(lambda: AudioVisualSaliencyModel(cfg), 0).to(dev)
-    clips, audio = T.synth_inputs(8, 16, 224, 224, Wa=300, seed=1, device=dev)
+    clips, audio = T.synth_inputs(B, 16, 224, 224, Wa=300, seed=1, device=dev)
     out, loss = m(clips, audio)
-    assert tuple(out.shape) == (8, 224, 224) and torch.isfinite(out).all() and torch.isfinite(loss)
+    assert tuple(out.shape) == (B, 224, 224) and torch.isfinite(out).all() and torch.isfinite(loss)
     assert torch.logsumexp(out.flatten(1), 1).abs().max().item() < 1e-4
     out2, _ = m(clips, audio)
     assert torch.equal(out, out2)                           # no atomics anywhere: bitwise reproducible
