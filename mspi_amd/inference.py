@@ -4,7 +4,9 @@ Same functions (`normalize, get_audio_feature, blur, process, inference_dataset,
 flags, same output files `save_path/<video>/<frame name>`; what differs:
   * the model forward and the map post-processing (blur -> exp -> resize -> min-max -> uint8) run on the GPU
     through the C ABI; one uint8 map comes back per frame instead of an fp32 map + five OpenCV passes;
-  * sliding windows are independent, so `--batch` windows go through one forward;
+  * sliding windows are independent, so `--batch` windows go through one forward, and that forward + the post-process
+    kernels are ONE captured hipGraph per frame shape, replayed with two batches in flight (`runtime.GraphPipeline`)
+    while the host encodes the previous batch's JPEGs (`--no_graph` launches eagerly instead);
   * the wav is read and resampled once per video, not once per frame (inference.py:28-31 does it per window), lives on
     the GPU, and the log-spectrogram windows of a batch are ONE kernel launch (`preproc.log_spectrogram`);
   * frames are decoded on the host (PIL) and resized + normalised on the GPU with PIL's own fixed-point bilinear
@@ -152,11 +154,71 @@ def process(model, frames, frame_idx, vname, img_size, audio_feature=None, args=
     else:
         pred = model(frames, **kw)[0]
     maps = E.postprocess_u8(pred, (img_size[1], img_size[0])).cpu().numpy()      # img_size is (W, H) as in cv2.resize
-    from PIL import Image
     os.makedirs(os.path.join(args.save_path, vname), exist_ok=True)
     names = frame_idx if isinstance(frame_idx, (list, tuple)) else [frame_idx]
+    _write_maps(maps, names, vname, args)
+
+
+def _write_maps(maps, names, vname, args):
+    from PIL import Image
     for name, m in zip(names, maps):
-        Image.fromarray(m).save(os.path.join(args.save_path, vname, name))
+        # quality=95 is cv2.imwrite's default IMWRITE_JPEG_QUALITY (the reference writes with cv2, inference.py:90); PIL's
+        # own default of 75 would change every saved map and the metrics computed from the files
+        Image.fromarray(m).save(os.path.join(args.save_path, vname, name), quality=95)
+
+
+class _WindowRunner:
+    """The clip loop's launch path: model forward + post-processing of a batch of `bs` windows as one hipGraph per input
+    shape (frames are all resized to one resolution, so a run captures once), two batches in flight.  `run()` queues a
+    batch and hands back the PREVIOUS batch's uint8 maps, so the host's JPEG encoding overlaps the GPU's next batch."""
+
+    def __init__(self, model, bs, img_size, use_sound, depth=2):
+        self.model, self.bs, self.img_size, self.use_sound, self.depth = model, bs, img_size, use_sound, depth
+        self.pipe, self.key, self.prev = None, None, None
+
+    def _fn(self, cached):
+        from . import engine as E
+        model, out_hw = self.model, (self.img_size[1], self.img_size[0])      # img_size is (W, H) as in cv2.resize
+
+        def fn(*t):
+            clips, rest = t[0], list(t[1:])
+            args = [clips] + ([rest.pop(0)] if self.use_sound else [])
+            kw = {"frame_feats": (rest[0], rest[1])} if cached else {}
+            return E.postprocess_u8(model(*args, **kw)[0], out_hw)
+        return fn
+
+    def run(self, inputs, names, vname, args, cached):
+        """inputs: (clips[, audio][, f1, f0]) for n <= bs windows -> writes nothing itself; returns (maps, names, vname)
+        of the previously queued batch, or None."""
+        from .runtime import GraphPipeline
+        n = inputs[0].shape[0]
+        if n < self.bs:                     # last, partial batch of a video: pad by repeating the final window
+            T = inputs[0].shape[2]
+            padded = []
+            for t in inputs:
+                per = t.shape[0] // n       # 1 for clips / audio, T for the (b t)-ordered frame features
+                padded.append(torch.cat([t, t[-per:].repeat((self.bs - n,) + (1,) * (t.dim() - 1))]))
+            inputs = padded
+        key = tuple(tuple(t.shape) for t in inputs) + (cached,)
+        if self.key != key:
+            out = self.finish()
+            if out is not None:
+                _write_maps(*out, args)
+            self.pipe = GraphPipeline(self._fn(cached), [t.to(device) for t in inputs], depth=self.depth)
+            self.key = key
+        ticket = self.pipe.submit(*[t.to(device, non_blocking=True) for t in inputs])
+        done, self.prev = self.prev, (ticket, n, names, vname)
+        return self._collect(done)
+
+    def _collect(self, rec):
+        if rec is None:
+            return None
+        ticket, n, names, vname = rec
+        return self.pipe.fetch(ticket)[:n].cpu().numpy(), names, vname
+
+    def finish(self):
+        out, self.prev = self._collect(self.prev), None
+        return out
 
 
 def torch_transform(path):
@@ -170,7 +232,7 @@ def torch_transform(path):
     return t, sz                                                       # resize + ToTensor + Normalize on the GPU
 
 
-def _flush(model, batch, vname, img_size, args, feats=None):
+def _flush(model, batch, vname, img_size, args, feats=None, runner=None):
     if not batch:
         return
     clips = torch.stack([b[0] for b in batch])
@@ -187,7 +249,13 @@ def _flush(model, batch, vname, img_size, args, feats=None):
     if feats is not None:     # (b t) order: the windows' frame indices, reversed for the time-reversed windows
         idx = [j for b in batch for j in b[3]]
         ff = (torch.stack([feats[j][0] for j in idx]), torch.stack([feats[j][1] for j in idx]))
-    process(model, clips, [b[2] for b in batch], vname, img_size, audio_feature=auds, args=args, frame_feats=ff)
+    if runner is None:
+        process(model, clips, [b[2] for b in batch], vname, img_size, audio_feature=auds, args=args, frame_feats=ff)
+    else:
+        inputs = [clips] + ([auds] if args.use_sound else []) + (list(ff) if ff is not None else [])
+        out = runner.run(inputs, [b[2] for b in batch], vname, args, ff is not None)
+        if out is not None:
+            _write_maps(*out, args)
     batch.clear()
 
 
@@ -234,6 +302,7 @@ def inference_dataset(model, args):
     list_data = list_data[rank::world]            # videos are independent units: shard, no collective
     print(list_data)
     bs = max(1, getattr(args, "batch", 1))
+    runner = _WindowRunner(model, bs, (640, 480), args.use_sound) if getattr(args, "graph", True) else None
     for vname in list_data:
         print("Processing: " + vname)
         audio_path = os.path.join(args.path_data, "video_audio", args.dataset, vname, vname + ".wav")
@@ -270,13 +339,17 @@ def inference_dataset(model, args):
                     batch.append((torch.flip(clip, [1]), (st, ln, 1), os.path.basename(list_frames[first]),
                                   list(range(i, first - 1, -1)), wave))
                 if len(batch) >= bs:
-                    _flush(model, batch, vname, img_size, args, cache.feats if cache else None)
+                    _flush(model, batch, vname, img_size, args, cache.feats if cache else None, runner)
                     if cache is not None:
                         cache.drop_before(first + 1)
                 del snippet[0]
                 for j in [j for j in loaded if j <= first and (cache is None or j < cache.next)]:
                     del loaded[j]
-        _flush(model, batch, vname, img_size, args, cache.feats if cache else None)
+        _flush(model, batch, vname, img_size, args, cache.feats if cache else None, runner)
+        if runner is not None:               # the last batch in flight
+            out = runner.finish()
+            if out is not None:
+                _write_maps(*out, args)
 
 
 def build_model(model_name, resolution, wa=111, weight=None, use_sound=True):
@@ -307,6 +380,8 @@ if __name__ == "__main__":
     parser.add_argument("--model", default=os.environ.get("MSPI_MOTION_ENCODER", "mvitv2s"), type=str)
     parser.add_argument("--resolution", default=[224, 384], type=int, nargs=2, help="H W the frames are resized to")
     parser.add_argument("--batch", default=8, type=int, help="sliding windows per forward")
+    parser.add_argument("--no_graph", dest="graph", action="store_false",
+                        help="launch every kernel eagerly instead of replaying one hipGraph per batch of windows")
     parser.add_argument("--no_frame_cache", dest="cache_frames", action="store_false",
                         help="re-encode all 16 frames of every window with the image encoder, as upstream does")
     args = parser.parse_args()

@@ -208,9 +208,9 @@ def test_frame_feature_cache(dev, tmp_path):
     b = model(clips, aud, frame_feats=(f1[flat], f0[flat]))[0]
     assert (a - b).abs().max().item() < 1e-5
     out = {}
-    for tag, cache in (("cached", True), ("plain", False)):
+    for tag, cache, graph in (("cached", True, True), ("plain", False, True), ("eager", True, False)):
         args = types.SimpleNamespace(clip_size=16, dataset="TOY", split=2, path_data=root, save_path=str(tmp_path / tag),
-                                     use_sound=True, batch=4, cache_frames=cache)
+                                     use_sound=True, batch=4, cache_frames=cache, graph=graph)
         I.inference_dataset(model, args)
         names = sorted(os.listdir(os.path.join(args.save_path, "clip1")))
         assert len(names) == 36
@@ -219,3 +219,5 @@ def test_frame_feature_cache(dev, tmp_path):
     # neighbouring grey level; the files went through a JPEG encode, which can turn that one level into two on a few pixels
     d = np.abs(out["cached"] - out["plain"])
     assert d.max() <= 2 and (d > 1).mean() < 1e-3
+    # hipGraph replay (runtime.GraphPipeline, two batches in flight, padded last batch) == eager launches, file for file
+    assert np.array_equal(out["cached"], out["eager"])

@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""Sliding-window throughput (stride 1, as inference.py walks a video) with and without the per-frame feature cache.
-Synthetic frames already on the GPU; eager launches, autotuned tiles; windows/s = maps written per second."""
+"""Sliding-window throughput (stride 1, as inference.py walks a video): eager launches vs the product's launch path
+(runtime.GraphPipeline: forward + post-process kernels as one hipGraph, two batches in flight), each with and without the
+per-frame feature cache.  Synthetic frames already on the GPU; autotuned tiles; windows/s = uint8 maps produced per second."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mspi_amd import engine as E, testing as T
 from mspi_amd.model.model_utils import AudioVisualSaliencyModel
+from mspi_amd.runtime import GraphPipeline
 
 dev = torch.device("cuda")
 name = sys.argv[1] if len(sys.argv) > 1 else "x3dl"
-B, n_frames = 8, 16 + 8 * 12
+B, n_frames = 8, 16 + 8 * 16
 t_tok = {"x3dl": 16, "slowfast4x16": 4, "s3d": 4}.get(name, 8)
 cfg = T.make_cfg(name, num_aud_tokens=90, num_vis_tokens=t_tok * 49)
 so, sys.stdout = sys.stdout, open(os.devnull, "w")
@@ -19,6 +21,7 @@ g = torch.Generator().manual_seed(0)
 video = torch.randn(n_frames, 3, 224, 224, generator=g).to(dev)
 aud = torch.randn(B, 1, 257, 300, generator=g).to(dev)
 E.autotune(True)
+OUT = (480, 640)
 
 
 def windows(first):
@@ -27,15 +30,13 @@ def windows(first):
     return clips, [j for w in idx for j in w]
 
 
-def run(cached):
-    feats = {}
-    nxt = 0
-    t0 = None
-    n = 0
+def run(cached, graph):
+    feats, nxt, t0, n, out, pipe, prev = {}, 0, None, 0, None, None, None
     for step, first in enumerate(range(0, n_frames - 16 - B + 1, B)):
-        if step == 2:                      # two warm-up batches (tuning, allocator)
+        if step == 3:                      # three warm-up batches (tuning, allocator, capture)
             torch.cuda.synchronize(); t0 = time.perf_counter(); n = 0
         clips, flat = windows(first)
+        inputs = [clips, aud]
         if cached:
             while nxt <= flat[-1]:
                 hi = min(n_frames, nxt + 16)
@@ -43,18 +44,34 @@ def run(cached):
                 for j in range(nxt, hi):
                     feats[j] = (f1[j - nxt], f0[j - nxt])
                 nxt = hi
-            ff = (torch.stack([feats[j][0] for j in flat]), torch.stack([feats[j][1] for j in flat]))
-            out = m(clips, aud, frame_feats=ff)[0]
+            inputs += [torch.stack([feats[j][0] for j in flat]), torch.stack([feats[j][1] for j in flat])]
             for j in [j for j in feats if j < first + B]:
                 del feats[j]
+        fn = (lambda c, a, f1, f0: E.postprocess_u8(m(c, a, frame_feats=(f1, f0))[0], OUT)) if cached else \
+             (lambda c, a: E.postprocess_u8(m(c, a)[0], OUT))
+        if graph:
+            if pipe is None:
+                pipe = GraphPipeline(fn, inputs, depth=2)
+            t = pipe.submit(*inputs)
+            if prev is not None:
+                out = pipe.fetch(prev).cpu()         # the previous batch's maps come to the host while this one runs
+            prev = t
         else:
-            out = m(clips, aud)[0]
+            out = fn(*inputs).cpu()
         n += B
+    if graph:
+        out = pipe.fetch(prev).cpu()
     torch.cuda.synchronize()
     return n / (time.perf_counter() - t0), out
 
 
-r_plain, o_plain = run(False)
-r_cache, o_cache = run(True)
-print("%s: %.1f windows/s re-encoding every window, %.1f windows/s with the per-frame cache (x%.2f); last batch max |diff| %.2e" % (
-    name, r_plain, r_cache, r_cache / r_plain, (o_plain - o_cache).abs().max().item()))
+res = {}
+for cached in (False, True):
+    for graph in (False, True):
+        res[cached, graph] = run(cached, graph)
+print("%s, batch %d, windows/s incl. post-processing and D2H of the uint8 maps:" % (name, B))
+print("  re-encoding every window : eager %.1f, hipGraph pipeline %.1f" % (res[False, False][0], res[False, True][0]))
+print("  per-frame feature cache  : eager %.1f, hipGraph pipeline %.1f" % (res[True, False][0], res[True, True][0]))
+print("  last batch, graph vs eager: %s; cache vs plain max |diff| %d grey levels" % (
+    "identical" if torch.equal(res[True, True][1], res[True, False][1]) and torch.equal(res[False, True][1], res[False, False][1]) else "DIFFERENT",
+    (res[True, True][1].int() - res[False, True][1].int()).abs().max().item()))
