@@ -204,7 +204,7 @@ class _WindowRunner:
             out = self.finish()
             if out is not None:
                 _write_maps(*out, args)
-            self.pipe = GraphPipeline(self._fn(cached), [t.to(device) for t in inputs], depth=self.depth)
+            self.pipe = GraphPipeline(self._fn(cached), [t.to(device) for t in inputs], depth=self.depth, host_outputs=True)
             self.key = key
         ticket = self.pipe.submit(*[t.to(device, non_blocking=True) for t in inputs])
         done, self.prev = self.prev, (ticket, n, names, vname)
@@ -214,7 +214,8 @@ class _WindowRunner:
         if rec is None:
             return None
         ticket, n, names, vname = rec
-        return self.pipe.fetch(ticket)[:n].cpu().numpy(), names, vname
+        return self.pipe.fetch(ticket)[:n].numpy(), names, vname    # pinned host buffer of that slot: written out before the
+                                                                    # slot is submitted again
 
     def finish(self):
         out, self.prev = self._collect(self.prev), None
@@ -285,7 +286,19 @@ class _FrameFeatureCache:
 
 def inference_dataset(model, args):
     """Sliding 16-frame window, stride 1; the first 15 frames come from the time-reversed first windows
-    (inference.py:94-152)."""
+    (inference.py:94-152).  The loop's own launches (frame resize, spectrogram windows, per-frame feature cache) go to a
+    non-blocking side stream: on torch's default stream -- HIP's NULL stream -- each of them would be an implicit barrier
+    against the hipGraph batches in flight (runtime.py)."""
+    if device.type != "cuda":
+        raise RuntimeError("mspi_amd.inference needs an MI355X (no CPU fallback)")
+    side = torch.cuda.Stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        _inference_dataset(model, args)
+    torch.cuda.current_stream(device).wait_stream(side)
+
+
+def _inference_dataset(model, args):
     len_temporal = args.clip_size
     if args.dataset == "DIEM":
         file_name = "DIEM_list_test_fps.txt"

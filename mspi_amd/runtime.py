@@ -21,7 +21,7 @@ import torch
 
 
 class _Slot:
-    __slots__ = ("stream", "graph", "inputs", "outs", "done", "busy")
+    __slots__ = ("stream", "graph", "inputs", "outs", "host", "done", "busy")
 
 
 class GraphPipeline:
@@ -32,10 +32,14 @@ class GraphPipeline:
                                    (the example, or whatever was last submitted) are used and no cross-stream wait exists
     fetch(ticket)   -> outputs    wait for that replay; the tensors are the slot's static outputs, valid until the slot
                                    is submitted again (`depth` submits later)
+    host_outputs=True: every replay is followed ON ITS OWN STREAM by an asynchronous copy of the outputs into pinned host
+    buffers, and fetch() returns those (a `.cpu()` by the caller would run on the NULL stream and drain the other batch
+    in flight).
     """
 
-    def __init__(self, fn, example_inputs, depth=2, layouts=1, log=None, capture_error_mode="thread_local"):
+    def __init__(self, fn, example_inputs, depth=2, layouts=1, log=None, capture_error_mode="thread_local", host_outputs=False):
         self.fn, self.depth = fn, max(1, int(depth))
+        self.host_outputs = bool(host_outputs)
         self.example = tuple(example_inputs)
         if not all(torch.is_tensor(t) and t.is_cuda for t in self.example):
             raise ValueError("GraphPipeline needs device-resident example inputs (there is no CPU path)")
@@ -73,9 +77,18 @@ class GraphPipeline:
         with torch.cuda.graph(s.graph, stream=s.stream, capture_error_mode=self._mode):
             out = self.fn(*s.inputs)
         s.outs = out if isinstance(out, (tuple, list)) else (out,)
+        s.host = tuple(torch.empty(o.shape, dtype=o.dtype, pin_memory=True) for o in s.outs) if self.host_outputs else None
         s.done = torch.cuda.Event()
         s.busy = False
         return s
+
+    def _behind_replay(self, k, s):
+        if self.after is not None:
+            self.after(k, s.outs)
+        if s.host is not None:
+            for h, o in zip(s.host, s.outs):
+                h.copy_(o, non_blocking=True)
+        s.done.record()
 
     @staticmethod
     def _rate(slots, n=8):
@@ -111,15 +124,11 @@ class GraphPipeline:
                     dst.copy_(t, non_blocking=True)
                     t.record_stream(s.stream)
                 s.graph.replay()
-                if self.after is not None:
-                    self.after(k, s.outs)
-                s.done.record()
+                self._behind_replay(k, s)
         else:
             with torch.cuda.stream(s.stream):
                 s.graph.replay()
-                if self.after is not None:
-                    self.after(k, s.outs)
-                s.done.record()
+                self._behind_replay(k, s)
         s.busy = True
         return k
 
@@ -128,7 +137,8 @@ class GraphPipeline:
         if s.busy:
             s.done.synchronize()
             s.busy = False
-        return s.outs if len(s.outs) > 1 else s.outs[0]
+        outs = s.host if s.host is not None else s.outs
+        return outs if len(outs) > 1 else outs[0]
 
     def drain(self):
         for k in range(self.depth):

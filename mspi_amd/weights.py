@@ -135,12 +135,33 @@ def convert_caffe2_blobs(blobs, model_state):
     return out, rep
 
 
+class _ArrayOnlyUnpickler(pickle.Unpickler):
+    """A model-zoo pickle is a downloaded file: plain `pickle.load` would run whatever callable it names.  A caffe2
+    checkpoint is a dict of str/bytes -> numpy arrays (plus scalars), so only numpy's array reconstruction helpers and
+    inert builtin containers may be resolved; any other global (os.system, builtins.eval, ...) is refused."""
+    _ALLOWED = {
+        ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy", "float32"), ("numpy", "float64"), ("numpy", "int32"), ("numpy", "int64"),
+        ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+        ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+        ("collections", "OrderedDict"), ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("builtins", "str"),
+        ("builtins", "bytes"), ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"),
+        ("__builtin__", "dict"), ("__builtin__", "list"), ("__builtin__", "tuple"), ("__builtin__", "str"),
+        ("__builtin__", "int"), ("__builtin__", "float"), ("__builtin__", "bool"),
+        ("_codecs", "encode"),             # protocol-2 pickles written by python 2 carry array bytes through it
+    }
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError("refusing to unpickle %s.%s: a caffe2 checkpoint holds numpy arrays only" % (module, name))
+
+
 def load_caffe2_pkl(path, model, strict_report=False):
     """Load a caffe2 model-zoo pickle (e.g. SLOWFAST_4x16_R50.pkl) into `model` (load_state_dict(strict=False), like
     upstream).  Returns the report of convert_caffe2_blobs; strict_report=True raises when a model parameter was not
     covered or a blob had the wrong shape."""
     with open(path, "rb") as f:
-        ck = pickle.load(f, encoding="latin1")
+        ck = _ArrayOnlyUnpickler(f, encoding="latin1").load()
     blobs = ck["blobs"] if isinstance(ck, dict) and "blobs" in ck else ck
     sd, rep = convert_caffe2_blobs(blobs, model.state_dict())
     if strict_report and (rep["missing"] or rep["shape_mismatch"]):

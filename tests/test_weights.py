@@ -74,3 +74,84 @@ def test_caffe2_shape_rules():
     assert sd["s1.pathway0_stem.bn.weight"].tolist() == [0, 1, 2, 3, 0, 1, 2, 3]
     assert "s1.pathway0_stem.bn.split_bn.running_mean" in sd
     assert [m[0] for m in rep["shape_mismatch"]] == ["res2_0_branch1_w"]
+
+
+def test_caffe2_pickle_with_code_is_refused(tmp_path):
+    """A checkpoint is a downloaded file: a pickle that names any callable outside numpy's array helpers must not load."""
+    class Evil:
+        def __reduce__(self):
+            import os as _os
+            return (_os.system, ("echo pwned > %s" % (tmp_path / "pwned"),))
+
+    for i, payload in enumerate(({"blobs": {"conv1_w": Evil()}}, Evil())):
+        path = str(tmp_path / ("evil%d.pkl" % i))
+        with open(path, "wb") as f:
+            pickle.dump(payload, f, protocol=2)
+        with pytest.raises(pickle.UnpicklingError, match="refusing"):
+            W.load_caffe2_pkl(path, _slowfast())
+    assert not (tmp_path / "pwned").exists()
+
+
+def _round_trip(make, wrap, path, strict_equal=True, extra=None):
+    """state dict of a seeded model -> `wrap`ped into the checkpoint layout upstream's loader expects -> torch.save ->
+    load_weight() on a differently seeded model -> tensors equal."""
+    src = T.seeded(make, 3)
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    ck = wrap(dict(sd))
+    if extra:
+        ck_inner = ck
+        while not any(torch.is_tensor(v) for v in ck_inner.values()):
+            ck_inner = next(v for v in ck_inner.values() if isinstance(v, dict))
+        ck_inner.update(extra)
+    torch.save(ck, path)
+    dst = T.seeded(make, 9)
+    assert any(not torch.equal(dst.state_dict()[k], v) for k, v in sd.items())
+    with contextlib.redirect_stdout(io.StringIO()):
+        dst.load_weight(path)
+    out = dst.state_dict()
+    for k, v in sd.items():
+        assert torch.equal(out[k], v), k
+
+
+def test_x3d_and_mvit_pyth_loaders(tmp_path):
+    """backbones/X3D.py:248-250 and MViT.py:2078-2081: the PySlowFast '.pyth' layout {'model_state': state_dict}, loaded
+    with strict=False (the released files also carry the classification head, which the feature extractor lacks)."""
+    from mspi_amd.backbones.MViT import MViT
+    from mspi_amd.backbones.X3D import X3D
+    from mspi_amd.config import cfg
+    head = {"head.projection.weight": torch.zeros(400, 2048), "head.projection.bias": torch.zeros(400)}
+    _round_trip(lambda: X3D(cfg.MODEL.X3D.PATH_CFG), lambda sd: {"model_state": sd, "epoch": 300}, str(tmp_path / "x3d_l.pyth"),
+                extra=head)
+    _round_trip(lambda: MViT(cfg.MODEL.MVIT2.PATH_CFG), lambda sd: {"model_state": sd}, str(tmp_path / "mvit.pyth"), extra=head)
+
+
+def test_swin_state_dict_loader(tmp_path):
+    """backbones/video_swin_transformer.py:593-605: mmaction layout {'state_dict': {'backbone.<key>': ...,
+    'cls_head.<key>': ...}}; only 'backbone.' entries are taken, prefix stripped."""
+    from mspi_amd.backbones.video_swin_transformer import SwinTransformer3D
+
+    def wrap(sd):
+        ck = {"backbone." + k: v for k, v in sd.items()}
+        ck["cls_head.fc_cls.weight"] = torch.zeros(400, 768)
+        return {"state_dict": ck, "meta": {"epoch": 30}}
+
+    _round_trip(lambda: SwinTransformer3D(depths=[2, 2, 6, 2]), wrap, str(tmp_path / "swin_tiny.pth"))
+
+
+def test_plain_state_dict_loaders(tmp_path):
+    """s3d.py:420-425 (bare state dict; a missing file raises), uniformer.py:497-500, MorphMLP.py:510-519 (head.* dropped)."""
+    from mspi_amd.backbones.MorphMLP import MorphMLP_32_features_only
+    from mspi_amd.backbones.s3d import S3D_features_only
+    from mspi_amd.backbones.uniformer import Uniformer
+    from mspi_amd.config import cfg
+    _round_trip(lambda: S3D_features_only(), lambda sd: sd, str(tmp_path / "s3d.pt"))
+    with pytest.raises(FileNotFoundError):
+        S3D_features_only().load_weight(str(tmp_path / "absent.pt"))
+    _round_trip(lambda: Uniformer(cfg.MODEL.UNIFORMER.PATH_CFG), lambda sd: sd, str(tmp_path / "uniformer.pth"))
+    _round_trip(lambda: MorphMLP_32_features_only(cfg.MODEL.MORPH.PATH_CFG), lambda sd: sd, str(tmp_path / "morph.pth"),
+                extra={"head.weight": torch.zeros(400, 784), "head.bias": torch.zeros(400)})
+
+
+def test_slowfast_pytorch_checkpoint_loader(tmp_path):
+    """mspi_amd/backbones/sf.py: PyTorch-format SlowFast checkpoints ({'model_state': ...}) load without the caffe2 path."""
+    _round_trip(_slowfast, lambda sd: {"model_state": sd}, str(tmp_path / "slowfast.pyth"))

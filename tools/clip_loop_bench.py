@@ -51,16 +51,16 @@ def run(cached, graph):
              (lambda c, a: E.postprocess_u8(m(c, a)[0], OUT))
         if graph:
             if pipe is None:
-                pipe = GraphPipeline(fn, inputs, depth=2)
+                pipe = GraphPipeline(fn, inputs, depth=2, host_outputs=True)
             t = pipe.submit(*inputs)
             if prev is not None:
-                out = pipe.fetch(prev).cpu()         # the previous batch's maps come to the host while this one runs
+                out = pipe.fetch(prev).clone()       # the previous batch's maps come to the host while this one runs
             prev = t
         else:
             out = fn(*inputs).cpu()
         n += B
     if graph:
-        out = pipe.fetch(prev).cpu()
+        out = pipe.fetch(prev).clone()
     torch.cuda.synchronize()
     return n / (time.perf_counter() - t0), out
 
