@@ -77,12 +77,8 @@ ARGS = parse() if __name__ == "__main__" else None
 if ARGS is not None and ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
     sys.exit(launch_ranks(ARGS.gpus))
 
-# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order.  Two graphs in flight x three
-# branch streams each overlap best when every one of them has its own queue: measured on the bench line, same box,
-# 4 queues 570 / 6 queues 595-601 / 8 queues 559 clips/s (and +2.8 % on mvitv2s).  With a process group RCCL's own
-# streams take queues too and the picture flips (4: 567, 5: 571, 6: 498, 7: 427; high-priority RCCL streams or touching the
-# pool streams before RCCL starts do not repair it reliably), so only the single-process run sets it.
-# Must happen before the HIP runtime initialises, i.e. before torch is imported; an explicit setting wins.
+# Single-process runs give every in-flight graph branch its own hardware queue (runtime.configure_hw_queues: must happen
+# before the HIP runtime initialises; multi-rank runs keep the default because RCCL's streams take queues too).
 if ARGS is not None and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("MSPI_BENCH_FORCE_DIST"):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
 
@@ -382,9 +378,19 @@ def main():
     # SURVEY 8d metric (2): saliency-map ms/clip INCLUDING the post-process kernels (inference.py:72-91: blur, exp, resize to
     # 640x480, min-max, uint8) -- the same pipeline with mspi_postprocess_u8 captured behind the forward, timed the same way.
     pp = None
+    lat_main = round(pipe.latency_ms(), 4) if pipe else None
+    layout_main = pipe.layout if pipe else None
     if pipe and not args.no_postproc:
+        # the forward-only pipeline is released first: which hardware queue a stream lands on follows creation order, and a
+        # second pipeline beside the first would share queues with it (measured: +6 ms latency from lost branch overlap)
+        pipe.after = None
+        outs = [o.clone() for o in outs]
+        pipe = None
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
         pipe_pp = GraphPipeline(lambda c, a: E.postprocess_u8(model(c, a)[0], (480, 640)), (clips, audio), depth=args.inflight,
-                                layouts=1)
+                                layouts=args.stream_layouts, log=log)
+        counter[0] = 0
         el_pp = timed(pipe_pp.submit, lambda: None)
         u8 = pipe_pp.fetch(0)
         if not (u8.dtype == torch.uint8 and tuple(u8.shape) == (B, 480, 640) and int(u8.max()) == 255 and int(u8.min()) == 0):
@@ -392,6 +398,7 @@ def main():
         pp = {"ms_per_clip_with_postproc": round(1e3 * el_pp / args.steps / B, 4),
               "latency_ms_per_batch_with_postproc": round(pipe_pp.latency_ms(), 4)}
         del pipe_pp, u8
+    graph_mode = not args.no_graph
 
     if rank != 0:
         if multi:
@@ -409,16 +416,16 @@ def main():
                                "forward), batch %d/GPU, clips 3x16x%dx%d, spectrogram 1x257x%d, inputs resident in HBM"
                                % (label, B, S, S, args.wa),
                    "global_batch": world * B,
-                   "launch": "eager" if not pipe else "hipGraph replay (mspi_amd.runtime.GraphPipeline), %d batch%s in flight"
+                   "launch": "eager" if not graph_mode else "hipGraph replay (mspi_amd.runtime.GraphPipeline), %d batch%s in flight"
                              % (depth, "es" if depth > 1 else ""),
-                   "stream_layout": pipe.layout if pipe else None,
+                   "stream_layout": layout_main,
                    "parallelism": "clip-sharded x%d (weights broadcast once, maps gathered per step over RCCL)" % world
                    if multi else "single GPU"},
     }
     if pp:
         line.update(pp)
-    if pipe:         # latency of ONE batch alone on the chip (no neighbouring batch in flight): median of 7 replays
-        line["latency_ms_per_batch"] = round(pipe.latency_ms(), 4)
+    if graph_mode:   # latency of ONE batch alone on the chip (no neighbouring batch in flight): median of 7 replays
+        line["latency_ms_per_batch"] = lat_main
         line["saliency_map_ms_per_clip"] = round((pp["latency_ms_per_batch_with_postproc"] if pp else line["latency_ms_per_batch"]) / B, 4)
 
     if not args.no_roofline:

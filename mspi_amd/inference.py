@@ -31,7 +31,12 @@ import torch
 IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
 
-device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+if __name__ == "__main__" and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    # one hardware queue per in-flight graph branch (runtime.configure_hw_queues); the HIP runtime reads this when it
+    # initialises, i.e. at the first HIP call below
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+
+device = torch.device("cuda" if torch.cuda.device_count() > 0 else "cpu")
 _RESOLUTION = [224, 384]     # (H, W) the frames are resized to; set from the CLI
 _AUDIO_CACHE = {}
 
@@ -204,7 +209,8 @@ class _WindowRunner:
             out = self.finish()
             if out is not None:
                 _write_maps(*out, args)
-            self.pipe = GraphPipeline(self._fn(cached), [t.to(device) for t in inputs], depth=self.depth, host_outputs=True)
+            self.pipe = GraphPipeline(self._fn(cached), [t.to(device) for t in inputs], depth=self.depth, host_outputs=True,
+                                      layouts=3)
             self.key = key
         ticket = self.pipe.submit(*[t.to(device, non_blocking=True) for t in inputs])
         done, self.prev = self.prev, (ticket, n, names, vname)

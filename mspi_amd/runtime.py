@@ -15,9 +15,22 @@ Rules the implementation keeps (each measured, DESIGN.md section 3 "Scheduling")
   * which hardware queue a stream lands on follows creation order, so `layouts` > 1 tries a few creation orders during
     the untimed set-up and keeps the fastest (two graphs x three branch streams overlap best on distinct queues).
 """
+import os
 import time
 
 import torch
+
+
+def configure_hw_queues(n=6):
+    """HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order.  Two graphs in flight x three
+    branch streams each overlap best when every one of them has its own queue: bench line, same box, 4 queues 570 / 6 queues
+    595-601 / 8 queues 559 clips/s.  With a process group RCCL's own streams take queues too and the picture flips (4: 567,
+    5: 571, 6: 498), so only single-process runs call this.  The runtime reads the variable when it initialises: call before
+    the first HIP call of the process (an explicit setting in the environment wins).  Returns whether it took effect."""
+    if torch.cuda.is_initialized():
+        return False
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(n))
+    return True
 
 
 class _Slot:

@@ -4,6 +4,7 @@
 per-frame feature cache.  Synthetic frames already on the GPU; autotuned tiles; windows/s = uint8 maps produced per second."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")      # as mspi_amd.inference's entry does (runtime.configure_hw_queues)
 import torch
 from mspi_amd import engine as E, testing as T
 from mspi_amd.model.model_utils import AudioVisualSaliencyModel
@@ -51,7 +52,7 @@ def run(cached, graph):
              (lambda c, a: E.postprocess_u8(m(c, a)[0], OUT))
         if graph:
             if pipe is None:
-                pipe = GraphPipeline(fn, inputs, depth=2, host_outputs=True)
+                pipe = GraphPipeline(fn, inputs, depth=2, host_outputs=True, layouts=3)
             t = pipe.submit(*inputs)
             if prev is not None:
                 out = pipe.fetch(prev).clone()       # the previous batch's maps come to the host while this one runs
@@ -66,9 +67,13 @@ def run(cached, graph):
 
 
 res = {}
-for cached in (False, True):
-    for graph in (False, True):
-        res[cached, graph] = run(cached, graph)
+side = torch.cuda.Stream()      # the loop's own launches stay off the NULL stream, as in inference.inference_dataset
+with torch.cuda.stream(side):
+    for cached in (False, True):
+        for graph in (False, True):
+            res[cached, graph] = run(cached, graph)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
 print("%s, batch %d, windows/s incl. post-processing and D2H of the uint8 maps:" % (name, B))
 print("  re-encoding every window : eager %.1f, hipGraph pipeline %.1f" % (res[False, False][0], res[False, True][0]))
 print("  per-frame feature cache  : eager %.1f, hipGraph pipeline %.1f" % (res[True, False][0], res[True, True][0]))
