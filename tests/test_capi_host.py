@@ -291,3 +291,23 @@ def test_morphmlp_factory_and_keys():
     assert {"patch_embed1.proj1.weight", "patch_embed1.norm2.running_var", "patch_embed4.norm.bias", "blocks1.2.t_fc.mlp_t.bias",
             "blocks3.8.fc.mlp_w.weight", "blocks3.0.fc.reweight.fc2.bias", "blocks4.2.fc.mlp_h.weight", "blocks2.3.mlp.fc1.weight"} <= keys
     assert "blocks4.0.fc.mlp_w.weight" not in keys and m.blocks4[0].fc.reweight.fc2.out_features == 2 * 784
+
+
+def test_library_has_no_cross_half_packed_fp32():
+    """The built gfx950 code must not contain packed-fp32 instructions whose low result reads the HIGH half of a source
+    (`v_pk_*_f32 ... op_sel:[..1..]`): on MI355X that form returns wrong low halves ~1e-7 of the time while another
+    stream's MFMA kernel shares the CU (tools/pk_overlap_probe.hip).  hipcc's SLP vectoriser emits
+    it for broadcast coefficients, which is why csrc/Makefile builds with -fno-slp-vectorize."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_no_packed_f32", os.path.join(root, "tools", "check_no_packed_f32.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    if not os.path.exists(chk.OBJDUMP):
+        pytest.skip("llvm-objdump not found")
+    n_obj, found = chk.packed_f32(os.path.join(root, "mspi_amd", "csrc", "libmspi_hip.so"))
+    assert n_obj >= 1
+    bad = [f for f in found if chk.cross_half(f[1])]
+    assert not bad, bad[:5]
+    assert chk.cross_half("v_pk_mul_f32 v[0:1], v[2:3], v[0:1] op_sel:[0,1] op_sel_hi:[0,1]")
+    assert not chk.cross_half("v_pk_add_f32 v[16:17], v[16:17], v[2:3] neg_lo:[0,1] neg_hi:[0,1]")
