@@ -206,6 +206,31 @@ int mspi_mvit_qk_augment_p(const MspiMvitAugDesc* d, const float* q, const float
                            mspi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * X3D block, first half, fused (csrc/x3d_block.hip):
+ *   u = act( b_bn( dw3x3x3( relu( a_bn( a(x) ) ) ) ) ),  act = SWISH (blocks without squeeze-excite) or NONE (+ pool)
+ * Replaces X3DTransform's a, a_bn, a_relu, b, b_bn (SlowFast/resnet_helper.py:296-319) for the stride-1 blocks; the
+ * 2.25x-wide `a` output stays in LDS.  x: [N,T,H,W] rows of ldx floats (Cin stored channels, Cin % 8 == 0); u: rows of
+ * ldu floats (Cmid stored channels).  wa_packed: mspi_x3d_ab_packed_bytes(Cin, Cmid) bytes, f16 hi/lo of a's weights
+ * (BN folded) times wa_scale in MFMA fragment order [chunk of 32 outputs][k32 step][16-row half][hi,lo][lane][8]: element
+ * e of lane l = W[chunk*32 + half*16 + (l & 15)][32*step + 8*(l >> 4) + e], zero padded.  wb: fp32 [27][Cmid] taps
+ * (kt,kh,kw major) with b_bn folded, bias_a / bias_b fp32.  pool (optional): [N][mspi_x3d_ab_pool_rows(d)][Cmid] partial
+ * sums of the PRE-activation output for mspi_se_gate (one row per workgroup, no atomics).
+ * H % 7 == 0 and (W % 14 == 0 or W == 7); Cin <= 96 or Cin in (160, 192]. */
+typedef struct MspiX3dAbDesc {
+  int32_t N, T, H, W;
+  int32_t Cin, Cmid;               /* stored channel counts */
+  int64_t ldx, ldu;
+  int32_t act;                     /* MSPI_ACT_NONE or MSPI_ACT_SWISH, applied to u (not to the pooled sums) */
+  float wa_scale;                  /* power-of-two pre-scale of a's weights */
+} MspiX3dAbDesc;
+
+int mspi_x3d_ab_supported(const MspiX3dAbDesc* d);
+int mspi_x3d_ab_pool_rows(const MspiX3dAbDesc* d);
+size_t mspi_x3d_ab_packed_bytes(int32_t Cin, int32_t Cmid);
+int mspi_x3d_ab_fwd(const MspiX3dAbDesc* d, const void* x, const void* wa_packed, const void* bias_a, const void* wb,
+                    const void* bias_b, void* u, void* pool /*or NULL*/, mspi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Max pooling, channels-last, -inf padding.
  * Replaces nn.MaxPool3d / MaxPool2d at model/model_utils.py:189,206;
  *   backbones/resnet.py:82; SlowFast/stem_helper.py:195-197; backbones/MViT.py:1403-1409.

@@ -84,6 +84,15 @@ class RowGemmDesc(C.Structure):
     ]
 
 
+class X3dAbDesc(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("Cin", C.c_int32), ("Cmid", C.c_int32),
+        ("ldx", C.c_int64), ("ldu", C.c_int64),
+        ("act", C.c_int32), ("wa_scale", C.c_float),
+    ]
+
+
 class PermuteDesc(C.Structure):
     _fields_ = [("dims", C.c_int32 * 6), ("strides", C.c_int64 * 6), ("src_elems", C.c_int64)]
 
@@ -130,6 +139,10 @@ _SIGNATURES = {
     "mspi_rowgemm_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "mspi_rowgemm_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "mspi_rowgemm_fwd": (C.c_int, [C.POINTER(RowGemmDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "mspi_x3d_ab_supported": (C.c_int, [C.POINTER(X3dAbDesc)]),
+    "mspi_x3d_ab_pool_rows": (C.c_int, [C.POINTER(X3dAbDesc)]),
+    "mspi_x3d_ab_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "mspi_x3d_ab_fwd": (C.c_int, [C.POINTER(X3dAbDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "mspi_mlp_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "mspi_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mspi_postprocess_workspace": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

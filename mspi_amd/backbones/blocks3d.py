@@ -8,6 +8,8 @@ hold parameters.  `run()` executes the block on channels-last activations (engin
      = conv(a) ; dwconv(b, pool sums) ; se_gate ; conv(c, gate+swish on the A operand, +res, ReLU)
   bottleneck  a:Tx1x1+BN+ReLU -> b:1x3x3+BN+ReLU -> c:1x1x1+BN (+skip) -> ReLU  = 3 (4) convs
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -128,6 +130,14 @@ class Swish(nn.Module):
     pass
 
 
+# Fused a+b kernel (csrc/x3d_block.hip) vs thin GEMM + depthwise kernel.  Measured per launch at batch 8, hipGraph-timed
+# (tools/x3d_ab_bench.py): 56x56 maps 93.7 vs 100.2 us, 28x28 62.5 vs 58.9, 14x14 50.2 vs 40.0, 7x7 43.5 vs 30.4 -- the
+# fused form wins only where the maps are large enough to be bandwidth-bound, so "auto" fuses those.
+# MSPI_X3D_FUSE = 0 (never) | 1 (every stride-1 block the kernel covers) | auto (default)
+FUSE_AB = os.environ.get("MSPI_X3D_FUSE", "auto")
+FUSE_MIN_W = 56
+
+
 class X3DTransform(HipModule):
     def __init__(self, dim_in, dim_out, temp_kernel_size, stride, dim_inner, num_groups, stride_1x1=False,
                  eps=1e-5, bn_mmt=0.1, dilation=1, se_ratio=0.0625, swish_inner=True, block_idx=0):
@@ -156,6 +166,8 @@ class X3DTransform(HipModule):
                                E.ACT_NONE if has_se else E.ACT_SWISH),
             "c": E.pack_conv(self.c.weight, None, self.c_bn, (1, 1, 1), (0, 0, 0), E.ACT_RELU, cin_stored=cs_mid),
         }
+        # stride-1 blocks: `a` + `b` as one launch, the 2.25x-wide tensor between them stays in LDS (csrc/x3d_block.hip)
+        pk["ab"] = E.pack_x3d_ab(pk["a"], pk["b"]) if FUSE_AB != "0" else None
         if has_se:
             f, c = self.se.fc1.out_channels, self.se.fc1.in_channels
             dev = self.se.fc1.weight.device
@@ -170,6 +182,12 @@ class X3DTransform(HipModule):
     def run(self, x, res, out=None):
         """res: skip tensor added before the final ReLU."""
         pk = self.pk
+        if pk["ab"] is not None and (FUSE_AB == "1" or x.W >= FUSE_MIN_W) and E.x3d_ab_supported(x, pk["ab"]):
+            if "se" in pk:
+                u, part = E.x3d_ab(x, pk["ab"], pool=True)
+                gate = E.se_gate(part, 1.0 / (u.T * u.H * u.W), *pk["se"])
+                return E.conv(u, pk["c"], res=res, gate=gate, out=out)
+            return E.conv(E.x3d_ab(x, pk["ab"]), pk["c"], res=res, out=out)
         t = E.conv(x, pk["a"])
         if "se" in pk:
             u, part = E.dwconv(t, pk["b"], pool=True)

@@ -415,6 +415,63 @@ def pack_dwconv(weight, bias=None, bn=None, stride=(1, 1, 1), pad=(0, 0, 0), act
     return p
 
 
+class PackedX3dAb:
+    __slots__ = ("wa", "ba", "wb", "bb", "wa_scale", "cin_s", "cmid", "cmid_s")
+
+
+def pack_x3d_ab(pa, pb):
+    """Operands of the fused X3D `a` + `b` kernel (mspi_x3d_ab_fwd) from the packed 1x1x1 conv `pa` (PackedConv, f16x3: BN
+    folded, scaled hi/lo planes) and the packed 3x3x3 depthwise conv `pb` (PackedDw); None when the layer pair is outside
+    the kernel's range.  Fragment order of wa: include/mspi_hip.h."""
+    if pa.prec != PREC_F16X3 or pa.k != (1, 1, 1) or pa.stride != (1, 1, 1) or pb.k != (3, 3, 3) or pb.stride != (1, 1, 1) \
+            or pb.pad != (1, 1, 1) or pa.cout_s != pb.c_s or pa.cin_s % 8 or pa.act != ACT_RELU or pa.bias is None:
+        return None
+    ks = (pa.cin_s + 31) // 32
+    if ks not in (1, 2, 3, 6):
+        return None
+    nch = (pa.cout_s + 31) // 32
+    dev = pa.w.device
+    ws = torch.zeros(nch * 32, ks * 32, dtype=torch.float32)
+    ws[:pa.cout_s, :pa.cin_s] = (pa.w[0].float() + pa.w[1].float()).cpu()[:, :pa.cin_s]     # hi + lo = the scaled fp32 weight's 22 bits
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    planes = [pl.view(nch, 2, 16, ks, 4, 8).permute(0, 3, 1, 4, 2, 5).reshape(nch, ks, 2, 64, 8) for pl in (hi, lo)]
+    p = PackedX3dAb()
+    p.wa = torch.stack(planes, 3).contiguous().to(dev)        # [nch, ks, half, plane, lane, 8]
+    p.ba, p.wb, p.bb = pa.bias, pb.w, pb.bias
+    p.wa_scale, p.cin_s, p.cmid, p.cmid_s = pa.w_scale, pa.cin_s, pb.c, pb.c_s
+    return p
+
+
+def _x3d_ab_desc(x, pk, out_ld, act):
+    d = _lib.X3dAbDesc()
+    d.N, d.T, d.H, d.W = x.N, x.T, x.H, x.W
+    d.Cin, d.Cmid, d.ldx, d.ldu, d.act, d.wa_scale = pk.cin_s, pk.cmid_s, x.ld, out_ld, act, pk.wa_scale
+    return d
+
+
+def x3d_ab_supported(x, pk):
+    return pk is not None and x.dense and x.Cs == pk.cin_s and bool(_lib.load().mspi_x3d_ab_supported(C.byref(_x3d_ab_desc(x, pk, pk.cmid_s, ACT_NONE))))
+
+
+def x3d_ab(x, pk, pool=False):
+    """u = act(b_bn(dw3x3x3(relu(a_bn(a(x)))))) in one launch (csrc/x3d_block.hip); pool=True: no activation, also returns
+    the [N, rows, C] partial sums of u for the squeeze-excite gate (X3DTransform with SE); otherwise act = Swish."""
+    lib = _lib.load()
+    _need_gpu(x.buf)
+    out = alloc(x.N, x.T, x.H, x.W, pk.cmid, x.buf.device)
+    d = _x3d_ab_desc(x, pk, out.ld, ACT_NONE if pool else ACT_SWISH)
+    part = None
+    if pool:
+        rows = lib.mspi_x3d_ab_pool_rows(C.byref(d))
+        part = torch.empty(x.N, rows, pk.cmid_s, dtype=torch.float32, device=x.buf.device)
+    with _Timed("x3d_ab_pool" if pool else "x3d_ab", 2.0 * x.M * (pk.cin_s + 27) * pk.cmid, 4.0 * x.M * (x.C + pk.cmid),
+                "in=%s Cin=%d Cmid=%d" % ((x.N, x.T, x.H, x.W), x.C, pk.cmid)):
+        check(lib.mspi_x3d_ab_fwd(C.byref(d), x.ptr, pk.wa.data_ptr(), pk.ba.data_ptr(), pk.wb.data_ptr(), pk.bb.data_ptr(),
+                                  out.ptr, part.data_ptr() if pool else None, _stream()), "mspi_x3d_ab_fwd")
+    return (out, part) if pool else out
+
+
 def _pad_vec(v, n):
     out = torch.zeros(n, dtype=torch.float32, device=v.device)
     out[: v.numel()] = v.detach().float().view(-1)
@@ -935,15 +992,21 @@ def gated_sum(srcs, logit, out=None):
     return out
 
 
-def postprocess_u8(logmap, out_hw):
-    """[N,H,W] log-probability maps (GPU) -> uint8 [N,Ho,Wo] grey maps (GPU): blur, exp, resize, min-max, round."""
+def postprocess_u8(logmap, out_hw, out=None):
+    """[N,H,W] log-probability maps (GPU) -> uint8 [N,Ho,Wo] grey maps: blur, exp, resize, min-max, round.
+    out: where the last kernel writes -- a device tensor (default: a new one) or a PINNED host tensor, which the kernel
+    addresses directly (no D2H copy is queued; the caller synchronises on an event behind the launch before reading)."""
     lib = _lib.load()
     _need_gpu(logmap)
     N, H, W = logmap.shape
     Ho, Wo = out_hw
     logmap = logmap.contiguous()
     ws = torch.empty(lib.mspi_postprocess_workspace(N, H, W, Ho, Wo), dtype=torch.uint8, device=logmap.device)
-    out = torch.empty(N, Ho, Wo, dtype=torch.uint8, device=logmap.device)
+    if out is None:
+        out = torch.empty(N, Ho, Wo, dtype=torch.uint8, device=logmap.device)
+    elif not (out.dtype == torch.uint8 and tuple(out.shape) == (N, Ho, Wo) and out.is_contiguous()
+              and (out.is_cuda or out.is_pinned())):
+        raise MspiError("postprocess_u8: out must be a contiguous uint8 [N,Ho,Wo] device tensor or pinned host tensor")
     check(lib.mspi_postprocess_u8(logmap.data_ptr(), out.data_ptr(), ws.data_ptr(), N, H, W, Ho, Wo, _stream()),
           "mspi_postprocess_u8")
     return out

@@ -186,10 +186,10 @@ class _WindowRunner:
         model, out_hw = self.model, (self.img_size[1], self.img_size[0])      # img_size is (W, H) as in cv2.resize
 
         def fn(*t):
-            clips, rest = t[0], list(t[1:])
+            clips, rest, host = t[0], list(t[1:-1]), t[-1]
             args = [clips] + ([rest.pop(0)] if self.use_sound else [])
             kw = {"frame_feats": (rest[0], rest[1])} if cached else {}
-            return E.postprocess_u8(model(*args, **kw)[0], out_hw)
+            E.postprocess_u8(model(*args, **kw)[0], out_hw, out=host)     # the quantise kernel writes the pinned host buffer
         return fn
 
     def run(self, inputs, names, vname, args, cached):
@@ -209,8 +209,8 @@ class _WindowRunner:
             out = self.finish()
             if out is not None:
                 _write_maps(*out, args)
-            self.pipe = GraphPipeline(self._fn(cached), [t.to(device) for t in inputs], depth=self.depth, host_outputs=True,
-                                      layouts=3)
+            self.pipe = GraphPipeline(self._fn(cached), [t.to(device) for t in inputs], depth=self.depth, layouts=3,
+                                      host_out=[((self.bs, self.img_size[1], self.img_size[0]), torch.uint8)])
             self.key = key
         ticket = self.pipe.submit(*[t.to(device, non_blocking=True) for t in inputs])
         done, self.prev = self.prev, (ticket, n, names, vname)

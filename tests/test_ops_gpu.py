@@ -572,3 +572,53 @@ def test_presplit_ln_gemm_gemm_chain(dev, M, C, Hd):
         E.conv(xcl, p1, sp_out=True)
     with pytest.raises(MspiError, match="1x1x1"):
         E.conv(sp, E.pack_conv(torch.randn(8, C, 1, 3, 3, generator=g), None, None, (1, 1, 1), (0, 1, 1), device=dev))
+
+
+X3D_AB_CASES = [
+    # (N, Cin, Cmid, T, H, W): the four stride-1 block shapes of X3D-L (reduced frames) + ragged T / single frame
+    (2, 24, 54, 5, 14, 28),      # s2: K = 24 (k32 step 3/4 used), 54 -> 56 stored, 2 chunks (second: 24 of 32 channels)
+    (2, 48, 108, 4, 7, 14),      # s3
+    (3, 96, 216, 6, 14, 14),     # s4: two spatial tiles per frame, 7 chunks
+    (2, 192, 432, 5, 7, 7),      # s5: 7x7 tiles, K = 192
+    (1, 96, 216, 1, 7, 14),      # a single frame: both temporal neighbours are padding
+    (1, 48, 108, 16, 14, 14),    # long clip: several T segments
+]
+
+
+@pytest.mark.parametrize("case", X3D_AB_CASES)
+@pytest.mark.parametrize("se", [False, True])
+def test_x3d_ab_fused(dev, case, se):
+    """mspi_x3d_ab_fwd: relu(a_bn(a(x))) -> dw3x3x3 + b_bn (-> Swish | -> SE partial sums) in one launch, against the
+    plain torch fp32 ops of X3DTransform.forward (SlowFast/resnet_helper.py:296-327), and bit for bit against itself."""
+    from mspi_amd import engine as E
+    if E.DEFAULT_PREC != E.PREC_F16X3:
+        pytest.skip("the fused X3D kernel is an f16x3 kernel")
+    N, Cin, Cmid, T, H, W = case
+    g = torch.Generator().manual_seed(Cin + Cmid + T)
+    x = torch.randn(N, Cin, T, H, W, generator=g)
+    wa = torch.randn(Cmid, Cin, 1, 1, 1, generator=g) / math.sqrt(Cin)
+    ba = torch.randn(Cmid, generator=g) * 0.3
+    wb = torch.randn(Cmid, 1, 3, 3, 3, generator=g) / math.sqrt(27)
+    bb = torch.randn(Cmid, generator=g) * 0.3
+    t = F.relu(F.conv3d(x.double(), wa.double(), ba.double()))
+    ref = F.conv3d(t, wb.double(), bb.double(), 1, 1, 1, Cmid)
+    from mspi_amd.module import to_cl
+    xc = to_cl(x.to(dev))
+    pa = E.pack_conv(wa, ba, act=E.ACT_RELU, cin_stored=xc.Cs, device=dev)
+    pb = E.pack_dwconv(wb, bb, None, (1, 1, 1), (1, 1, 1), E.ACT_NONE if se else E.ACT_SWISH, device=dev)
+    pk = E.pack_x3d_ab(pa, pb)
+    assert pk is not None and E.x3d_ab_supported(xc, pk)
+    if se:
+        u, part = E.x3d_ab(xc, pk, pool=True)
+        _close(u.as_ncdhw(Cmid), ref.float(), 2e-5, "x3d a+b")
+        _close(part.sum(1)[:, :Cmid], ref.sum((2, 3, 4)).float(), 2e-5, "x3d a+b: se partial sums")
+        u2, part2 = E.x3d_ab(xc, pk, pool=True)
+        assert torch.equal(u.buf, u2.buf) and torch.equal(part, part2)
+        if u.Cs > Cmid:
+            assert (part[:, :, Cmid:] == 0).all()
+    else:
+        u = E.x3d_ab(xc, pk)
+        _close(u.as_ncdhw(Cmid), F.silu(ref).float(), 2e-5, "x3d a+b + swish")
+    # the unfused pair of launches computes the same thing
+    v = E.dwconv(E.conv(xc, pa), pb)
+    _close(u.as_ncdhw(Cmid), v.as_ncdhw(Cmid).cpu(), 2e-5, "fused vs unfused")

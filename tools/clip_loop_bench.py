@@ -48,11 +48,11 @@ def run(cached, graph):
             inputs += [torch.stack([feats[j][0] for j in flat]), torch.stack([feats[j][1] for j in flat])]
             for j in [j for j in feats if j < first + B]:
                 del feats[j]
-        fn = (lambda c, a, f1, f0: E.postprocess_u8(m(c, a, frame_feats=(f1, f0))[0], OUT)) if cached else \
-             (lambda c, a: E.postprocess_u8(m(c, a)[0], OUT))
+        fn = (lambda c, a, f1, f0, out=None: E.postprocess_u8(m(c, a, frame_feats=(f1, f0))[0], OUT, out=out)) if cached else \
+             (lambda c, a, out=None: E.postprocess_u8(m(c, a)[0], OUT, out=out))
         if graph:
             if pipe is None:
-                pipe = GraphPipeline(fn, inputs, depth=2, host_outputs=True, layouts=3)
+                pipe = GraphPipeline(fn, inputs, depth=2, layouts=3, host_out=[((B,) + OUT, torch.uint8)])
             t = pipe.submit(*inputs)
             if prev is not None:
                 out = pipe.fetch(prev).clone()       # the previous batch's maps come to the host while this one runs

@@ -15,7 +15,7 @@ m = T.seeded(lambda: AudioVisualSaliencyModel(cfg), 0).to(dev)
 sys.stdout = so
 clips, aud = T.synth_inputs(8, 16, 224, 224, Wa=300, seed=1, device=dev)
 E.autotune(True); m(clips, aud); E.autotune(False)
-fn = lambda c, a: E.postprocess_u8(m(c, a)[0], (480, 640))
+fn = lambda c, a, out=None: E.postprocess_u8(m(c, a)[0], (480, 640), out=out)
 N = 24
 
 
@@ -46,7 +46,7 @@ def loop(pipe, mode, host):
 
 side = torch.cuda.Stream()
 for host in (False, True):
-    pipe = GraphPipeline(fn, (clips, aud), depth=2, layouts=3, host_outputs=host)
+    pipe = GraphPipeline(fn, (clips, aud), depth=2, layouts=3, host_out=[((8, 480, 640), torch.uint8)] if host else None)
     for stream_name, ctx in (("null stream", None), ("side stream", side)):
         for mode in ("resident", "same", "fresh"):
             if ctx is None:
