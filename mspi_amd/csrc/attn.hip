@@ -31,6 +31,7 @@ struct AttnArgs {
   int B, Hh, Nq, Nk, nmask, nwin;
   long q_sB, q_sH, q_sT, k_sB, k_sH, k_sT, v_sB, v_sH, v_sT, o_sB, o_sH, o_sT;
   float scale;
+  int single;
 };
 
 // D = head dim of Q/K (the contraction of S), DV = head dim of V / O.  They differ for MViT, whose decomposed
@@ -305,8 +306,10 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
     for (int st = 0; st < NS; ++st) {
       const v8h kh = *reinterpret_cast<const v8h*>(&Kh[li * KP + 16 * st + 8 * lh]);
       const v8h kl = *reinterpret_cast<const v8h*>(&Kl[li * KP + 16 * st + 8 * lh]);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], s, 0, 0, 0);
+      if (!p.single) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], s, 0, 0, 0);
+      }
       s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], s, 0, 0, 0);
     }
 #pragma unroll
@@ -367,8 +370,10 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
         const v4h c1 = *reinterpret_cast<const v4h*>(&Vl[d * VP + 16 * s2 + 8 + 4 * lh]);
         const v8h vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         const v8h vl = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s2], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s2], acc[t], 0, 0, 0);
+        if (!p.single) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s2], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s2], acc[t], 0, 0, 0);
+        }
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s2], acc[t], 0, 0, 0);
       }
   }
@@ -590,6 +595,7 @@ extern "C" int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float*
   a.q = q; a.k = k; a.v = v; a.res = res; a.biasT = biasT; a.maskT = maskT; a.tok_idx = tok_idx; a.o = o;
   a.B = d->B; a.Hh = d->Hh; a.Nq = d->Nq; a.Nk = d->Nk; a.nmask = d->nmask > 0 ? d->nmask : 1;
   a.nwin = d->nwin > 0 ? d->nwin : 1;
+  a.single = single_product();
   a.q_sB = d->q_sB; a.q_sH = d->q_sH; a.q_sT = d->q_sT;
   a.k_sB = d->k_sB; a.k_sH = d->k_sH; a.k_sT = d->k_sT;
   a.v_sB = d->v_sB; a.v_sH = d->v_sH; a.v_sT = d->v_sT;

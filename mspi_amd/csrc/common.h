@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 #include "../../include/mspi_hip.h"
 
 namespace mspi {
@@ -28,6 +29,14 @@ inline int check_launch(const char* what) {
       return MSPI_EINVAL;         \
     }                             \
   } while (0)
+
+// MSPI_F16_PRODUCTS=1: measurement switch -- every f16x3 kernel issues only the hi*hi MFMA of its three split products, i.e.
+// plain f16 operands with fp32 accumulation (BASELINE configs[4] "fp16 MFMA").  Same data path, a third of the MFMAs.
+// DESIGN.md section 5 records what that costs in accuracy on the golden vectors; the default (3) is the fp32-accurate product.
+inline int single_product() {
+  static const int v = (getenv("MSPI_F16_PRODUCTS") && atoi(getenv("MSPI_F16_PRODUCTS")) == 1) ? 1 : 0;
+  return v;
+}
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
