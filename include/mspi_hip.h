@@ -49,6 +49,14 @@ enum { MSPI_PREC_F32 = 0, MSPI_PREC_F16X3 = 1 };
 
 int mspi_version(void);
 const char* mspi_last_error(void);
+/* Range guard.  f16x3 operands must satisfy |x| < 65504 (beyond it the f16 hi half is inf).  The GEMM kernels (mspi_conv_fwd,
+ * mspi_conv_splitk_fwd, mspi_gemm_sp_fwd, mspi_rowgemm_fwd, mspi_mlp_fwd, mspi_x3d_ab_fwd) check their pre-activation
+ * results and store 1 into *word when one is inf or NaN -- whatever the cause (operand out of range, non-finite input).
+ * `word` must be device-visible: a 4-byte word of pinned host memory (hipHostMalloc / torch pin_memory) lets the caller read
+ * it without a device call, after the event that covers the launches; the caller clears it.  NULL (default): no report.
+ * Process-global; set it before launching from several threads. */
+int mspi_set_status_word(int32_t* device_visible_word);
+
 /* number of visible HIP devices whose arch is gfx950 (0 if none). */
 int mspi_device_count(void);
 

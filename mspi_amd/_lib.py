@@ -103,6 +103,7 @@ _SIGNATURES = {
     "mspi_version": (C.c_int, []),
     "mspi_last_error": (C.c_char_p, []),
     "mspi_device_count": (C.c_int, []),
+    "mspi_set_status_word": (C.c_int, [_P]),
     "mspi_conv_last_config": (C.c_int, []),
     "mspi_conv_splitk_ws_bytes": (C.c_size_t, [C.POINTER(ConvDesc), C.c_int32]),
     "mspi_conv_splitk_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_int32, _P]),

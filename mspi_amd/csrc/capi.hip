@@ -5,6 +5,8 @@ namespace mspi {
 
 static thread_local char g_err[512] = "";
 
+int* g_status_word = nullptr;
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -17,6 +19,11 @@ void set_error(const char* fmt, ...) {
 extern "C" int mspi_version(void) { return MSPI_ABI_VERSION; }
 
 extern "C" const char* mspi_last_error(void) { return mspi::g_err; }
+
+extern "C" int mspi_set_status_word(int32_t* device_visible_word) {
+  mspi::g_status_word = device_visible_word;
+  return MSPI_OK;
+}
 
 extern "C" int mspi_device_count(void) {
   int n = 0;

@@ -38,6 +38,12 @@ inline int single_product() {
   return v;
 }
 
+// Range guard of the f16x3 kernels.  An activation with |x| >= 65504 becomes inf in its f16 hi half and the product sums turn
+// into inf / NaN: every GEMM epilogue checks its pre-activation results and, on a non-finite one, stores 1 into the status
+// word the caller registered with mspi_set_status_word() -- a word of pinned HOST memory that kernels address directly, so the
+// caller reads it without a device synchronisation of its own (after the event that covers the launches).  NULL: no report.
+extern int* g_status_word;
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 rounding level): libm's erff inlines to
@@ -72,6 +78,11 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
   asm("" : "+v"(x));
   hi = (_Float16)x;
   lo = (_Float16)(x - (float)hi);
+}
+
+__device__ __forceinline__ bool nonfinite(float v) { return !(fabsf(v) <= 3.4028235e38f); }
+__device__ __forceinline__ void report_nonfinite(int* status, bool bad) {
+  if (bad && status) *reinterpret_cast<volatile int*>(status) = 1;   // idempotent: racing stores write the same value
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -37,6 +37,7 @@ struct ConvArgs {
   int rows_per_sample;
   int tiles_n, nblocks;
   float out_scale;  // F16X3: 1 / (power-of-two weight pre-scale), applied to the accumulator
+  int* status;      // range guard (common.h): set to 1 when an output is not finite; may be NULL
   int single;       // 1: hi*hi product only (common.h single_product())
   int dbg;          // ablation switches for tools/gemm_probe.py (MSPI_CONV_DBG); 0 in production
   int ksplit;       // split-K: gridDim.y workgroups share an output tile, each owns a contiguous range of K steps ...

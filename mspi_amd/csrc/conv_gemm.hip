@@ -337,6 +337,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  bool bad = false;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + li;
@@ -360,10 +361,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
       for (int r = 0; r < 16; ++r) {
         const int row = rb0 + (r & 3) + 8 * (r >> 2);
         const float v = (PREC == PREC_F32 ? acc[i][j][r] : acc[i][j][r] * p.out_scale) + bv + rv[r];
+        bad |= nonfinite(v);
         if (row < p.M) p.y[(long)row * p.ldy + col] = act_apply(v, p.act);
       }
     }
   }
+  report_nonfinite(p.status, bad);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -386,6 +389,7 @@ namespace mspi {
 int launch_conv_ad(ConvArgs& a, long Ml, int force_bn, int* cfg, hipStream_t s);
 int launch_conv_ad8(ConvArgs& a, long Ml, int bn, int* cfg, hipStream_t s);
 int launch_conv_sp(ConvArgs& a, long Ml, int bn, int rows, int* cfg, hipStream_t s);
+int launch_conv_sp2(ConvArgs& a, long Ml, int variant, int* cfg, hipStream_t s);   // conv_gemm_sp2.hip
 }
 
 static thread_local int g_last_cfg = 0;
@@ -395,8 +399,9 @@ namespace mspi {
 // y = act( sum_z ws[z] + bias + res ): the K slices' partial sums, added in slice order (bitwise reproducible)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, long M, int Cout,
                                                             const float* __restrict__ bias, const float* __restrict__ res,
-                                                            long ldr, float* __restrict__ y, long ldy, int act) {
+                                                            long ldr, float* __restrict__ y, long ldy, int act, int* status) {
   const long total = M * (Cout >> 2);
+  bool bad = false;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int c = (int)(idx % (Cout >> 2)) * 4;
     const long row = idx / (Cout >> 2);
@@ -407,9 +412,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
     if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + c); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
     if (res) { const float4 b = *reinterpret_cast<const float4*>(res + row * ldr + c); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    bad |= nonfinite(a.x) | nonfinite(a.y) | nonfinite(a.z) | nonfinite(a.w);
     a.x = act_apply(a.x, act); a.y = act_apply(a.y, act); a.z = act_apply(a.z, act); a.w = act_apply(a.w, act);
     *reinterpret_cast<float4*>(y + row * ldy + c) = a;
   }
+  report_nonfinite(status, bad);
 }
 }  // namespace mspi
 
@@ -453,6 +460,7 @@ static int conv_fwd_impl(const MspiConvDesc* d, const float* x, const float* w, 
   a.M = (int)Ml; a.K = (int)K; a.rows_per_sample = To * Ho * Wo;
   a.out_scale = d->prec == PREC_F16X3 ? 1.0f / d->w_scale : 1.0f;
   a.single = single_product();
+  a.status = g_status_word;
   static const int dbg = getenv("MSPI_CONV_DBG") ? atoi(getenv("MSPI_CONV_DBG")) : 0;
   a.dbg = dbg;
   a.ws = ws; a.ksplit = ksplit;
@@ -473,7 +481,7 @@ static int conv_fwd_impl(const MspiConvDesc* d, const float* x, const float* w, 
     const long total = Ml * (d->Cout >> 2);
     const long blocks = (total + 255) / 256;
     hipLaunchKernelGGL(mspi::splitk_reduce_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, ws, ksplit,
-                       Ml, d->Cout, bias, res, (long)d->ldr, y, (long)d->ldy, d->act);
+                       Ml, d->Cout, bias, res, (long)d->ldr, y, (long)d->ldy, d->act, mspi::g_status_word);
     return check_launch("mspi_conv_splitk_fwd");
   }
 
@@ -615,6 +623,7 @@ extern "C" int mspi_gemm_sp_fwd(const MspiConvDesc* d, const void* x_planes, int
   a.M = (int)Ml; a.K = d->C; a.rows_per_sample = d->T * d->H * d->W;
   a.out_scale = 1.0f / d->w_scale;
   a.single = single_product();
+  a.status = g_status_word;
   a.dbg = 0; a.ws = nullptr; a.ksplit = 1;
   a.xs = (const _Float16*)x_planes; a.ldxs = ldx; a.xplane = xplane;
   a.ys = (_Float16*)y_planes; a.ldys = ldys; a.yplane = yplane;
@@ -631,7 +640,8 @@ extern "C" int mspi_gemm_sp_fwd(const MspiConvDesc* d, const void* x_planes, int
     default: bn = d->Cout <= 64 ? 64 : (d->Cout % 192 == 0 ? 192 : 128); break;
   }
   int cfg = 0;
-  const int rc = launch_conv_sp(a, Ml, bn, rows, &cfg, (hipStream_t)stream);
+  const int rc = (d->tile >= 15 && d->tile <= 18) ? launch_conv_sp2(a, Ml, d->tile - 15, &cfg, (hipStream_t)stream)
+                                                  : launch_conv_sp(a, Ml, bn, rows, &cfg, (hipStream_t)stream);
   MSPI_REQUIRE(rc == 0, "mspi_gemm_sp_fwd: tile %d could not be launched", d->tile);
   g_last_cfg = cfg;
   return check_launch("mspi_gemm_sp_fwd");

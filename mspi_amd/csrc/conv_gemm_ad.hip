@@ -287,6 +287,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  bool bad = false;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + j * 32 + li;
@@ -315,7 +316,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int r = 2 * q + e;
-          const float v = act_apply(acc[j][r] * p.out_scale + bv + rv[r], p.act);
+          const float pre = acc[j][r] * p.out_scale + bv + rv[r];
+          bad |= nonfinite(pre);
+          const float v = act_apply(pre, p.act);
           _Float16 h, l;
           split_f16(v, h, l);
           h2 pr = {h, l};
@@ -339,10 +342,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = rb0 + (r & 3) + 8 * (r >> 2);
-      const float v = act_apply(acc[j][r] * p.out_scale + bv + rv[r], p.act);
-      if (row < p.M) p.y[(long)row * p.ldy + col] = v;
+      const float pre = acc[j][r] * p.out_scale + bv + rv[r];
+      bad |= nonfinite(pre);
+      if (row < p.M) p.y[(long)row * p.ldy + col] = act_apply(pre, p.act);
     }
   }
+  report_nonfinite(p.status, bad);
 }
 
 // returns 0 when launched, -100 when this path does not apply (caller falls back to conv_gemm.hip).

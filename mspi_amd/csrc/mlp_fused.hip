@@ -34,6 +34,7 @@ struct MlpArgs {
   int ln, act;
   float eps, inv_s1, inv_s2;
   int single;
+  int* status;
 };
 
 // Packed weight stage (one hidden chunk j of 32 units), all f16, 1 KB = 64 lanes x 8 halves per fragment:
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(256, (C == 96 && TM == 1) ? (NS == 2 ? 3 : 2) : 1) 
   }
 
   // ---- epilogue: lane (li, lh) holds, for row li, channels ct*32 + q*8 + 4*lh + 0..3
+  bool bad = false;
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
     const long row = row0 + t * 32 + li;
@@ -233,10 +235,12 @@ __global__ __launch_bounds__(256, (C == 96 && TM == 1) ? (NS == 2 ? 3 : 2) : 1) 
         v.y = fmaf(o[t][ct][q * 4 + 1], p.inv_s2, b.y) + rv[q].y;
         v.z = fmaf(o[t][ct][q * 4 + 2], p.inv_s2, b.z) + rv[q].z;
         v.w = fmaf(o[t][ct][q * 4 + 3], p.inv_s2, b.w) + rv[q].w;
+        bad |= nonfinite(v.x) | nonfinite(v.y) | nonfinite(v.z) | nonfinite(v.w);
         if (ok) *reinterpret_cast<float4*>(p.y + row * p.ldy + c) = v;
       }
     }
   }
+  report_nonfinite(p.status, bad);
 }
 
 template <int C, int TM, int NS>
@@ -273,6 +277,7 @@ extern "C" int mspi_mlp_fwd(const MspiMlpDesc* d, const void* x, const void* gam
   a.nch = d->hidden / 32; a.ln = d->ln; a.act = d->act; a.eps = d->eps;
   a.inv_s1 = 1.0f / d->w1_scale; a.inv_s2 = 1.0f / d->w2_scale;
   a.single = single_product();
+  a.status = g_status_word;
   static const int variant = getenv("MSPI_MLP_TM") ? atoi(getenv("MSPI_MLP_TM")) : 0;
   int rc;
   MSPI_REQUIRE(d->C != 96 || d->hidden <= 512, "mspi_mlp_fwd: hidden = %d > 512 with C = 96", d->hidden);
@@ -305,6 +310,7 @@ struct RowGemmArgs {
   float inv_s;
   int rows_per_sample;
   int single;
+  int* status;
 };
 
 constexpr int RG_LDS = 64 * 1024;   // dynamic LDS budget of one workgroup (rowgemm_cps keeps cps * (SB + 128) below it: no opt-in needed)
@@ -368,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void rowgemm_kernel(const RowGemmArgs p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  bool bad = false;
   for (int jl = 0; jl < nj; ++jl) {
     const int j = j0 + jl;
     const unsigned char* st = rg_smem + (long)jl * SB + lane * 16;
@@ -400,6 +407,7 @@ __global__ __launch_bounds__(256, 2) void rowgemm_kernel(const RowGemmArgs p) {
       v.y = fmaf(h[q * 4 + 1], p.inv_s, b.y) + rv[q].y;
       v.z = fmaf(h[q * 4 + 2], p.inv_s, b.z) + rv[q].z;
       v.w = fmaf(h[q * 4 + 3], p.inv_s, b.w) + rv[q].w;
+      bad |= nonfinite(v.x) | nonfinite(v.y) | nonfinite(v.z) | nonfinite(v.w);
       if (p.act == MSPI_ACT_RELU) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       } else if (p.act != MSPI_ACT_NONE) {
@@ -408,6 +416,7 @@ __global__ __launch_bounds__(256, 2) void rowgemm_kernel(const RowGemmArgs p) {
       if (rok && c < p.N) *reinterpret_cast<float4*>(p.y + row * p.ldy + c) = v;
     }
   }
+  report_nonfinite(p.status, bad);
 }
 
 template <int KSB>
@@ -461,6 +470,7 @@ extern "C" int mspi_rowgemm_fwd(const MspiRowGemmDesc* d, const void* x, const v
   a.K = d->K; a.N = d->N; a.nch = (d->N + 31) / 32; a.act = d->act; a.inv_s = 1.0f / d->w_scale;
   a.rows_per_sample = d->rows_per_sample;
   a.single = single_product();
+  a.status = g_status_word;
   const int ksb = rowgemm_ksb(d->K);
   a.cps = rowgemm_cps(d->M, a.nch, ksb);
   const size_t lds = (size_t)a.cps * (ksb * 2048 + 128);

@@ -98,14 +98,30 @@ __global__ __launch_bounds__(256) void minmax_reduce_kernel(const float* __restr
   }
 }
 
+// 16 pixels per thread, one 16-byte store: `out` may be pinned HOST memory (the clip loop reads the maps there), where
+// byte-sized stores cross PCIe one partial line at a time (measured: 2.3x slower clip loop than no output at all).
 __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__ y, const float* __restrict__ mm,
                                                        unsigned char* __restrict__ out, int L) {
   const int n = blockIdx.y;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int idx = (blockIdx.x * 256 + threadIdx.x) * 16;
   if (idx >= L) return;
   const float lo = mm[2 * n], hi = mm[2 * n + 1];
-  const float v = (y[(long)n * L + idx] - lo) / (hi - lo);
-  out[(long)n * L + idx] = (unsigned char)rintf(v * 255.f);   // np.round: half to even
+  const float inv = hi - lo;
+  const float* yp = y + (long)n * L + idx;
+  unsigned char* op = out + (long)n * L + idx;
+  if (idx + 16 <= L && (((long)n * L + idx) & 15) == 0) {
+    unsigned w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(yp + 4 * q);
+      const unsigned b0 = (unsigned)rintf((v.x - lo) / inv * 255.f), b1 = (unsigned)rintf((v.y - lo) / inv * 255.f);   // np.round: half to even
+      const unsigned b2 = (unsigned)rintf((v.z - lo) / inv * 255.f), b3 = (unsigned)rintf((v.w - lo) / inv * 255.f);
+      w[q] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    }
+    *reinterpret_cast<uint4*>(op) = make_uint4(w[0], w[1], w[2], w[3]);
+  } else {
+    for (int e = 0; e < 16 && idx + e < L; ++e) op[e] = (unsigned char)rintf((yp[e] - lo) / inv * 255.f);
+  }
 }
 
 }  // namespace mspi
@@ -142,6 +158,6 @@ extern "C" int mspi_postprocess_u8(const float* logmap, unsigned char* out, void
   hipLaunchKernelGGL(blur_exp_kernel, dim3((H * W + 255) / 256, N), dim3(256), 0, s, logmap, blurred, H, W);
   hipLaunchKernelGGL(resize_minmax_kernel, dim3(nb, N), dim3(256), 0, s, blurred, resized, H, W, Ho, Wo, part);
   hipLaunchKernelGGL(minmax_reduce_kernel, dim3(N), dim3(256), 0, s, part, nb, mm);
-  hipLaunchKernelGGL(quantize_kernel, dim3((Ho * Wo + 255) / 256, N), dim3(256), 0, s, resized, mm, out, Ho * Wo);
+  hipLaunchKernelGGL(quantize_kernel, dim3((Ho * Wo + 4095) / 4096, N), dim3(256), 0, s, resized, mm, out, Ho * Wo);
   return check_launch("mspi_postprocess_u8");
 }

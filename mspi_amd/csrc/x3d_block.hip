@@ -33,6 +33,7 @@ struct X3dAbArgs {
   int act;
   float inv_s;
   int single;
+  int* status;
   int dbg;      // ablation switches for tools/x3d_ab_bench.py (MSPI_X3D_DBG): 1 skip the GEMM phase, 2 skip the depthwise phase, 4 no x loads; 0 in production
 };
 
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(256, 2) void x3d_ab_kernel(const X3dAbArgs p) {
   for (int k = 0; k < 27; ++k) wreg[k] = cok ? *reinterpret_cast<const float4*>(p.wb + (long)k * p.Cmid + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 bq = cok ? *reinterpret_cast<const float4*>(p.bb + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
   float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool bad = false;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(256, 2) void x3d_ab_kernel(const X3dAbArgs p) {
           }
           // lane (li, kg): cell li of this B tile, channels at*16 + 4*kg + 0..3;  a_bn bias, ReLU, zero outside the frame
           const float4 bv = *reinterpret_cast<const float4*>(bias_a + at * 16 + 4 * kg);
+          bad |= inside && (nonfinite(acc[0]) | nonfinite(acc[1]) | nonfinite(acc[2]) | nonfinite(acc[3]));
           float4 o;
           o.x = inside ? fmaxf(fmaf(acc[0], p.inv_s, bv.x), 0.f) : 0.f;
           o.y = inside ? fmaxf(fmaf(acc[1], p.inv_s, bv.y), 0.f) : 0.f;
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void x3d_ab_kernel(const X3dAbArgs p) {
     }
     __syncthreads();
   }
+  report_nonfinite(p.status, bad);
   if (p.pool) {     // squeeze-excite partial sums of the pre-activation output: one row per workgroup, fixed order
     float* red = ring;                                      // all ring reads are behind the loop's last barrier
     *reinterpret_cast<float4*>(red + tid * 4) = psum;
@@ -284,6 +288,7 @@ extern "C" int mspi_x3d_ab_fwd(const MspiX3dAbDesc* d, const void* x, const void
   static const int tseg_env = getenv("MSPI_X3D_TSEG") ? atoi(getenv("MSPI_X3D_TSEG")) : 0;
   a.dbg = dbg;
   a.single = single_product();
+  a.status = g_status_word;
   x3d_geometry(d, a);
   if (tseg_env > 0 && !pool) { a.tseg = tseg_env; a.nseg = (d->T + a.tseg - 1) / a.tseg; }
   hipStream_t s = (hipStream_t)stream;

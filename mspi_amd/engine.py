@@ -140,6 +140,61 @@ def _stream():
 def _need_gpu(t):
     if not t.is_cuda:
         raise MspiError("mspi_amd runs on the GPU only (tensor on %s); there is no CPU fallback" % t.device)
+    if _STATUS["word"] is None:
+        _register_status_word()
+
+
+# ----------------------------------------------------------------------------- f16x3 operand range
+# f16x3 splits an fp32 operand into f16 hi + lo halves.  Weights are pre-scaled by a power of two at pack time; activations
+# are split as they are, which is exact to 2^-22 relative while 2^-5 <~ |x| < 65504 for the LARGEST entries of the tensor:
+# beyond 65504 the hi half is inf; far below, the lo half sinks into f16 subnormals (absolute error 2^-25 per element,
+# whatever its size).  Two safeguards:
+#  * RANGE GUARD (always on): the GEMM kernels store 1 into a pinned host word when a result is inf / NaN
+#    (mspi_set_status_word); range_flag() / check_range() read it -- no device call, the caller synchronises first.
+#  * RANGE CHECK on first sight of a pack (the first, autotuning forward -- the same "first input is representative"
+#    contract as cudnn.benchmark upstream, inference.py:19): max|x| of the layer's input outside [2^-5, 2^15] moves THAT layer
+#    to the fp32 MFMA path (exact fp32 fmaf chain, 5.3x the MFMA time) for good.  MSPI_RANGE_CHECK=0 disables it.
+_STATUS = {"word": None}
+RANGE_CHECK = {"on": _os.environ.get("MSPI_RANGE_CHECK", "1") != "0", "lo": 2.0 ** -5, "hi": 2.0 ** 15, "seen": set(), "moved": []}
+
+
+def _register_status_word():
+    w = torch.zeros(1, dtype=torch.int32).pin_memory()
+    check(_lib.load().mspi_set_status_word(w.data_ptr()), "mspi_set_status_word")
+    _STATUS["word"] = w
+
+
+def range_flag(reset=True):
+    """True when a GEMM kernel has produced a non-finite result since the last reset.  Host read of a pinned word: valid for
+    launches the caller has synchronised with (an event / stream / device sync)."""
+    w = _STATUS["word"]
+    if w is None:
+        return False
+    bad = bool(int(w[0]))
+    if bad and reset:
+        w[0] = 0
+    return bad
+
+
+def check_range(sync=True):
+    """Raise MspiError when an f16x3 GEMM has overflowed (or was fed non-finite data) since the last check."""
+    if sync and torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if range_flag():
+        raise MspiError("a GEMM produced inf/NaN: an activation left the f16x3 range (|x| >= 65504) or the input was not finite; "
+                        "let the first forward see representative data (engine.autotune(True): out-of-range layers move to the "
+                        "fp32 path) or run with MSPI_GEMM_PREC=f32")
+
+
+def _range_check(pk, amax_fn, what):
+    """First sight of a pack while tuning: move it to the fp32 path if its input's magnitude is outside the f16x3 window."""
+    if id(pk) in RANGE_CHECK["seen"]:
+        return
+    RANGE_CHECK["seen"].add(id(pk))
+    amax = float(amax_fn())
+    if not (amax == amax) or amax >= RANGE_CHECK["hi"] or 0.0 < amax < RANGE_CHECK["lo"]:
+        pk.w, pk.ldw, pk.prec, pk.thin, pk.w_scale = pk.w32, pk.ldw32, PREC_F32, None, 1.0
+        RANGE_CHECK["moved"].append((what, amax))
 
 
 class CL:
@@ -255,7 +310,8 @@ def fold_bn(weight, bias, bn):
 
 
 class PackedConv:
-    __slots__ = ("w", "bias", "k", "stride", "pad", "cin", "cin_s", "cout", "cout_s", "ldw", "act", "prec", "w_scale", "thin")
+    __slots__ = ("w", "bias", "k", "stride", "pad", "cin", "cin_s", "cout", "cout_s", "ldw", "act", "prec", "w_scale", "thin",
+                 "w32", "ldw32")
 
 
 def pack_conv(weight, bias=None, bn=None, stride=(1, 1, 1), pad=(0, 0, 0), act=ACT_NONE, cin_stored=None,
@@ -297,10 +353,13 @@ def pack_conv(weight, bias=None, bn=None, stride=(1, 1, 1), pad=(0, 0, 0), act=A
         hi = ws.to(torch.float16)
         lo = (ws - hi.float()).to(torch.float16)
         p.w = torch.stack([hi, lo]).to(dev).contiguous()
+        p.ldw32 = rup4(K)                                   # the fp32 form, for layers the range check moves off f16x3
+        p.w32 = wf[:, :p.ldw32].to(dev).contiguous()
         if (kt, kh, kw) == (1, 1, 1) and tuple(stride) == (1, 1, 1) and tuple(pad) == (0, 0, 0):
             p.thin = _pack_rowgemm(ws[:, :K], cin_s, cout_s, dev)
     else:
         p.w = wf.to(dev).contiguous()
+        p.w32, p.ldw32 = p.w, ldw
     if b is None:
         p.bias = None
     else:
@@ -483,7 +542,9 @@ def _out_extent(T, H, W, k, s, p):
     return ((T + 2 * p[0] - k[0]) // s[0] + 1, (H + 2 * p[1] - k[1]) // s[1] + 1, (W + 2 * p[2] - k[2]) // s[2] + 1)
 
 
-SP_TILES = (6, 7, 9, 10, 11, 12, 13, 14)      # mspi_gemm_sp_fwd: 128 x {128,64,96,192,256}, 256 x {256,192,128}
+# mspi_gemm_sp_fwd: 128 x {128,64,96,192,256}, 256 x {256,192,128}; 15..18 = the 2 x 2-wave kernel (conv_gemm_sp2.hip):
+# 128x128 ring 2 / ring 3, 128x256, 256x128
+SP_TILES = (6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18)
 
 
 def _conv_sp(x, pk, out, res, act, tile, sp_out):
@@ -532,7 +593,8 @@ def _conv_sp(x, pk, out, res, act, tile, sp_out):
     elif AUTOTUNE["on"] and not torch.cuda.is_current_stream_capturing():
         choice = AUTOTUNE["cache"].get(key)
         if choice is None:
-            choice = _tune_conv(launch, key, [t for t in SP_TILES if t < 12 or M >= 4096])
+            # 16..18 (deeper ring / wider 2 x 2-wave tiles) lost on every shape measured (profiles/r02_sp_probe.txt): not tuned
+            choice = _tune_conv(launch, key, [t for t in SP_TILES if t < 12 or (t <= 14 and M >= 4096) or t == 15])
     elif key in AUTOTUNE["cache"]:
         choice = AUTOTUNE["cache"][key]
     with _Timed("conv_gemm", 2.0 * M * pk.cin * pk.cout, 4.0 * (M * pk.cin + M * pk.cout * (2 if res is not None else 1) + pk.cout * pk.cin),
@@ -548,8 +610,18 @@ def conv(x, pk, out=None, res=None, gate=None, act=None, tile=None, sp_out=False
     """x: CL, or a raw 5-D [N,C,T,H,W] / 4-D [N,C,H,W] torch tensor with arbitrary strides.
     tile: force a kernel instantiation (MspiConvDesc.tile); None = autotune cache / library heuristic."""
     lib = _lib.load()
+    tuning = AUTOTUNE["on"] and RANGE_CHECK["on"] and pk.prec == PREC_F16X3 and not torch.cuda.is_current_stream_capturing()
     if isinstance(x, SP):
-        return _conv_sp(x, pk, out, res, act, tile, sp_out)
+        if tuning:   # planes: the hi plane carries the magnitude (an out-of-range layer is fixed from the NEXT forward on: its
+            #          producer stops emitting planes once this pack is fp32)
+            _range_check(pk, lambda: x.buf[: x.M * x.ld].view(x.M, x.ld)[:, : x.C].abs().max(), "planes -> %dx%d" % (pk.cin, pk.cout))
+        if pk.prec == PREC_F16X3:
+            return _conv_sp(x, pk, out, res, act, tile, sp_out)
+        raise MspiError("conv: this layer was moved to the fp32 path by the range check; run the forward again "
+                        "(its producer now hands over fp32 rows)")
+    if tuning:
+        _range_check(pk, (lambda: (x.as_rows()[:, : x.C] if x.dense else x.buf).abs().max()) if isinstance(x, CL) else (lambda: x.abs().max()),
+                     "conv %s %d -> %d" % (pk.k, pk.cin, pk.cout))
     if sp_out:
         raise MspiError("conv: split-plane output needs a split-plane input (mspi_gemm_sp_fwd)")
     d = ConvDesc()
@@ -825,7 +897,8 @@ def mlp_tail(x, packed, ln, eps, res):
     """res + fc2(GELU(fc1(LayerNorm(x)))) with packed = pack_mlp_tail(...), ln = (gamma, beta)."""
     if packed[0] == "fused":
         return mlp(x, packed[1], res=res, ln=ln, eps=eps)
-    if sp_supported(x.C) and sp_supported(packed[1].cout_s) and packed[1].ldw == x.C and packed[2].ldw == packed[1].cout_s:
+    if sp_supported(x.C) and sp_supported(packed[1].cout_s) and packed[1].ldw == x.C and packed[2].ldw == packed[1].cout_s \
+            and packed[1].prec == PREC_F16X3 and packed[2].prec == PREC_F16X3:
         # LN -> planes, fc1 + GELU -> planes, fc2 (+res) -> fp32 rows: no operand is converted inside a GEMM loop
         return conv(conv(layernorm(x, ln[0], ln[1], eps, sp=True), packed[1], sp_out=True), packed[2], res=res)
     return conv(conv(layernorm(x, ln[0], ln[1], eps), packed[1]), packed[2], res=res)

@@ -4,9 +4,10 @@ Same functions (`normalize, get_audio_feature, blur, process, inference_dataset,
 flags, same output files `save_path/<video>/<frame name>`; what differs:
   * the model forward and the map post-processing (blur -> exp -> resize -> min-max -> uint8) run on the GPU
     through the C ABI; one uint8 map comes back per frame instead of an fp32 map + five OpenCV passes;
-  * sliding windows are independent, so `--batch` windows go through one forward, and that forward + the post-process
-    kernels are ONE captured hipGraph per frame shape, replayed with two batches in flight (`runtime.GraphPipeline`)
-    while the host encodes the previous batch's JPEGs (`--no_graph` launches eagerly instead);
+  * sliding windows are independent, so `--batch` windows go through one forward; with `--graph` that forward + the
+    post-process kernels are ONE captured hipGraph per frame shape, replayed with two batches in flight
+    (`runtime.GraphPipeline`) while the host encodes the previous batch's JPEGs.  Off by default: in this loop the
+    runtime's graph launch stalls for ~60 ms every third batch (DESIGN.md section 3), which makes eager launches faster;
   * the wav is read and resampled once per video, not once per frame (inference.py:28-31 does it per window), lives on
     the GPU, and the log-spectrogram windows of a batch are ONE kernel launch (`preproc.log_spectrogram`);
   * frames are decoded on the host (PIL) and resized + normalised on the GPU with PIL's own fixed-point bilinear
@@ -34,7 +35,7 @@ IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
 if __name__ == "__main__" and int(os.environ.get("WORLD_SIZE", "1")) == 1:
     # one hardware queue per in-flight graph branch (runtime.configure_hw_queues); the HIP runtime reads this when it
     # initialises, i.e. at the first HIP call below
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # 2 graphs x 3 branches + this loop's stream + the D2H copy stream
 
 device = torch.device("cuda" if torch.cuda.device_count() > 0 else "cpu")
 _RESOLUTION = [224, 384]     # (H, W) the frames are resized to; set from the CLI
@@ -180,16 +181,17 @@ class _WindowRunner:
     def __init__(self, model, bs, img_size, use_sound, depth=2):
         self.model, self.bs, self.img_size, self.use_sound, self.depth = model, bs, img_size, use_sound, depth
         self.pipe, self.key, self.prev = None, None, None
+        self.loop_stream = None       # a stream on a hardware queue the graphs do not use, for the loop's own launches
 
     def _fn(self, cached):
         from . import engine as E
         model, out_hw = self.model, (self.img_size[1], self.img_size[0])      # img_size is (W, H) as in cv2.resize
 
         def fn(*t):
-            clips, rest, host = t[0], list(t[1:-1]), t[-1]
+            clips, rest = t[0], list(t[1:])
             args = [clips] + ([rest.pop(0)] if self.use_sound else [])
             kw = {"frame_feats": (rest[0], rest[1])} if cached else {}
-            E.postprocess_u8(model(*args, **kw)[0], out_hw, out=host)     # the quantise kernel writes the pinned host buffer
+            return E.postprocess_u8(model(*args, **kw)[0], out_hw)
         return fn
 
     def run(self, inputs, names, vname, args, cached):
@@ -197,6 +199,12 @@ class _WindowRunner:
         of the previously queued batch, or None."""
         from .runtime import GraphPipeline
         n = inputs[0].shape[0]
+        if n > self.bs:                     # the loop adds two windows per frame while the reversed ones last: split
+            per = [t.shape[0] // n for t in inputs]
+            first = self.run([t[: self.bs * k] for t, k in zip(inputs, per)], names[: self.bs], vname, args, cached)
+            if first is not None:
+                _write_maps(*first, args)
+            return self.run([t[self.bs * k:] for t, k in zip(inputs, per)], names[self.bs:], vname, args, cached)
         if n < self.bs:                     # last, partial batch of a video: pad by repeating the final window
             T = inputs[0].shape[2]
             padded = []
@@ -209,9 +217,12 @@ class _WindowRunner:
             out = self.finish()
             if out is not None:
                 _write_maps(*out, args)
-            self.pipe = GraphPipeline(self._fn(cached), [t.to(device) for t in inputs], depth=self.depth, layouts=3,
-                                      host_out=[((self.bs, self.img_size[1], self.img_size[0]), torch.uint8)])
+            self.pipe = GraphPipeline(self._fn(cached), [t.to(device) for t in inputs], depth=self.depth, layouts=3)
             self.key = key
+            idle = self.pipe.idle_streams(2)
+            self.pipe._copy_stream = idle[0]
+            idle[1].wait_stream(torch.cuda.current_stream())
+            self.loop_stream = idle[1]
         ticket = self.pipe.submit(*[t.to(device, non_blocking=True) for t in inputs])
         done, self.prev = self.prev, (ticket, n, names, vname)
         return self._collect(done)
@@ -220,8 +231,8 @@ class _WindowRunner:
         if rec is None:
             return None
         ticket, n, names, vname = rec
-        return self.pipe.fetch(ticket)[:n].numpy(), names, vname    # pinned host buffer of that slot: written out before the
-                                                                    # slot is submitted again
+        return self.pipe.fetch_host(ticket)[:n].numpy(), names, vname    # pinned host buffer of that slot: written out before
+                                                                         # the slot is fetched again
 
     def finish(self):
         out, self.prev = self._collect(self.prev), None
@@ -321,7 +332,7 @@ def _inference_dataset(model, args):
     list_data = list_data[rank::world]            # videos are independent units: shard, no collective
     print(list_data)
     bs = max(1, getattr(args, "batch", 1))
-    runner = _WindowRunner(model, bs, (640, 480), args.use_sound) if getattr(args, "graph", True) else None
+    runner = _WindowRunner(model, bs, (640, 480), args.use_sound) if getattr(args, "graph", False) else None
     for vname in list_data:
         print("Processing: " + vname)
         audio_path = os.path.join(args.path_data, "video_audio", args.dataset, vname, vname + ".wav")
@@ -346,6 +357,9 @@ def _inference_dataset(model, args):
         if getattr(args, "cache_frames", True) and hasattr(model, "encode_frames"):
             cache = _FrameFeatureCache(model, load_frame, len(list_frames))
         for i in range(len(list_frames)):
+            if runner is not None and runner.loop_stream is not None and torch.cuda.current_stream() != runner.loop_stream:
+                runner.loop_stream.wait_stream(torch.cuda.current_stream())
+                torch.cuda.set_stream(runner.loop_stream)         # from here on the loop launches on a free hardware queue
             snippet.append(load_frame(i))
             if i >= len_temporal - 1:
                 first = i - len_temporal + 1
@@ -369,6 +383,7 @@ def _inference_dataset(model, args):
             out = runner.finish()
             if out is not None:
                 _write_maps(*out, args)
+    torch.cuda.current_stream().synchronize()   # whichever stream the loop ended on (it moves to an idle hardware queue)
 
 
 def build_model(model_name, resolution, wa=111, weight=None, use_sound=True):
@@ -399,8 +414,8 @@ if __name__ == "__main__":
     parser.add_argument("--model", default=os.environ.get("MSPI_MOTION_ENCODER", "mvitv2s"), type=str)
     parser.add_argument("--resolution", default=[224, 384], type=int, nargs=2, help="H W the frames are resized to")
     parser.add_argument("--batch", default=8, type=int, help="sliding windows per forward")
-    parser.add_argument("--no_graph", dest="graph", action="store_false",
-                        help="launch every kernel eagerly instead of replaying one hipGraph per batch of windows")
+    parser.add_argument("--graph", dest="graph", action="store_true",
+                        help="replay one hipGraph per batch of windows, two batches in flight, instead of launching eagerly")
     parser.add_argument("--no_frame_cache", dest="cache_frames", action="store_false",
                         help="re-encode all 16 frames of every window with the image encoder, as upstream does")
     args = parser.parse_args()

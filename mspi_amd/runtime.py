@@ -21,7 +21,7 @@ import time
 import torch
 
 
-def configure_hw_queues(n=6):
+def configure_hw_queues(n=6):   # 6: pure replay of two graphs (bench.py); 8: plus a producer and a copy stream (the clip loop)
     """HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order.  Two graphs in flight x three
     branch streams each overlap best when every one of them has its own queue: bench line, same box, 4 queues 570 / 6 queues
     595-601 / 8 queues 559 clips/s.  With a process group RCCL's own streams take queues too and the picture flips (4: 567,
@@ -34,7 +34,7 @@ def configure_hw_queues(n=6):
 
 
 class _Slot:
-    __slots__ = ("stream", "graph", "inputs", "outs", "host", "done", "busy")
+    __slots__ = ("stream", "graph", "inputs", "outs", "host", "done", "busy", "keep")
 
 
 class GraphPipeline:
@@ -45,16 +45,17 @@ class GraphPipeline:
                                    (the example, or whatever was last submitted) are used and no cross-stream wait exists
     fetch(ticket)   -> outputs    wait for that replay; the tensors are the slot's static outputs, valid until the slot
                                    is submitted again (`depth` submits later)
-    host_out=[(shape, dtype), ...]: every slot owns pinned HOST tensors of these shapes, `fn(*inputs, *host_tensors)` makes
-    its last kernel write the results straight into them (pinned memory is device-addressable; the event behind the
-    replay is a system-scope release), and fetch() returns them.  Measured against the alternatives on the clip loop: an
-    asynchronous D2H copy queued behind the replay halves the throughput (603 -> 294 windows/s: the copy serialises the
-    two graphs in flight), and a `.cpu()` by the caller runs on the NULL stream, which drains them.
+    fetch_host(ticket) -> the same outputs in pinned HOST buffers of the slot: the copy is issued when the replay HAS
+    finished, on a copy stream of its own, and waited for -- the next batch keeps the GPU busy meanwhile.  Measured on the
+    clip loop (x3dl, batch 8, tools/submit_probe.py): letting the last kernel write pinned host memory directly, or queueing
+    the D2H copy on the replay's stream behind the graph, both HALVE the throughput (603 -> 264..303 windows/s: 38 k posted
+    PCIe writes on the graph's critical path / the copy serialising the two graphs in flight), and a `.cpu()` by the caller
+    runs on the NULL stream, which drains every batch in flight.
     """
 
-    def __init__(self, fn, example_inputs, depth=2, layouts=1, log=None, capture_error_mode="thread_local", host_out=None):
+    def __init__(self, fn, example_inputs, depth=2, layouts=1, log=None, capture_error_mode="thread_local"):
         self.fn, self.depth = fn, max(1, int(depth))
-        self.host_out = list(host_out or [])
+        self._copy_stream = None
         self.example = tuple(example_inputs)
         if not all(torch.is_tensor(t) and t.is_cuda for t in self.example):
             raise ValueError("GraphPipeline needs device-resident example inputs (there is no CPU path)")
@@ -83,19 +84,19 @@ class GraphPipeline:
         s.stream = torch.cuda.Stream()
         s.inputs = tuple(t.clone() for t in self.example)
         s.stream.wait_stream(torch.cuda.current_stream())
-        s.host = tuple(torch.empty(shape, dtype=dtype, pin_memory=True) for shape, dtype in self.host_out) or None
-        extra = s.host or ()
+        s.host = None
         with torch.cuda.stream(s.stream):
-            self.fn(*s.inputs, *extra)                             # warms this stream's allocator pools
+            self.fn(*s.inputs)                                     # warms this stream's allocator pools
         torch.cuda.current_stream().wait_stream(s.stream)
         torch.cuda.synchronize()
         s.graph = torch.cuda.CUDAGraph()
         # thread_local: the capture must not trip over HIP calls of other threads (the RCCL watchdog polls events)
         with torch.cuda.graph(s.graph, stream=s.stream, capture_error_mode=self._mode):
-            out = self.fn(*s.inputs, *extra)
+            out = self.fn(*s.inputs)
         s.outs = () if out is None else (tuple(out) if isinstance(out, (tuple, list)) else (out,))
         s.done = torch.cuda.Event()
         s.busy = False
+        s.keep = None
         return s
 
     def _behind_replay(self, k, s):
@@ -129,13 +130,19 @@ class GraphPipeline:
             for t, dst in zip(inputs, s.inputs):
                 if tuple(t.shape) != tuple(dst.shape):
                     raise ValueError("graph captured for %s, got %s" % (tuple(dst.shape), tuple(t.shape)))
+            if s.busy:
+                s.done.synchronize()                               # the batch this slot ran `depth` submits ago
+            # The caller's tensors are kept alive HERE until this slot's replay has been waited for -- not handed to the
+            # allocator with record_stream(): a block with a pending cross-stream use cannot be reused, so every submit grew
+            # the pool by a fresh hipMalloc, and hipMalloc synchronises the device (measured: a 50-75 ms stall every third
+            # batch of the clip loop).
+            s.keep = inputs
             produced = torch.cuda.Event()
             produced.record()                                      # on the producer's (current) stream
             with torch.cuda.stream(s.stream):
                 s.stream.wait_event(produced)
                 for t, dst in zip(inputs, s.inputs):
                     dst.copy_(t, non_blocking=True)
-                    t.record_stream(s.stream)
                 s.graph.replay()
                 self._behind_replay(k, s)
         else:
@@ -145,13 +152,70 @@ class GraphPipeline:
         s.busy = True
         return k
 
+    def submit_build(self, build):
+        """Like submit(*inputs), but `build(static_inputs)` fills the slot's input buffers itself and runs ON THE SLOT'S
+        STREAM, directly in front of the replay: the whole batch -- input assembly, forward, post-processing -- is one stream
+        with no cross-stream hand-over and no allocation outside that stream's pool.  The tensors `build` reads must be
+        complete (produced on this stream earlier, or synchronised by the caller)."""
+        k = self._count % self.depth
+        self._count += 1
+        s = self.slots[k]
+        with torch.cuda.stream(s.stream):
+            build(s.inputs)
+            s.graph.replay()
+            self._behind_replay(k, s)
+        s.busy = True
+        return k
+
     def fetch(self, ticket):
         s = self.slots[ticket]
         if s.busy:
             s.done.synchronize()
             s.busy = False
-        outs = s.host if s.host is not None else s.outs
-        return outs if len(outs) > 1 else outs[0]
+            s.keep = None
+        return s.outs if len(s.outs) > 1 else s.outs[0]
+
+    def idle_streams(self, k=1, candidates=10):
+        """k streams whose HARDWARE QUEUE no branch of the in-flight graphs uses.  HIP deals streams onto GPU_MAX_HW_QUEUES
+        queues in creation order, and work on a stream that shares a queue with a graph branch waits for every batch in
+        flight (measured: a 2.4 MB D2H copy, 0.1 ms on a free queue, completes after 24-26 ms on a shared one --
+        tools/d2h_probe.py).  Which queues the runtime gave the graphs' branches is not exposed, so this measures: with all
+        graphs replaying, a one-element kernel on each candidate; the quickest candidates sit on free queues.  Needs
+        GPU_MAX_HW_QUEUES > the graphs' 3 * depth branches (configure_hw_queues(8) for depth 2)."""
+        cands = [torch.cuda.Stream() for _ in range(candidates)]
+        probe = torch.zeros(1, device=self.example[0].device)
+        lat = []
+        for c in cands:
+            torch.cuda.synchronize()
+            for s in self.slots:
+                with torch.cuda.stream(s.stream):
+                    s.graph.replay()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(c):
+                probe.add_(1.0)
+                ev = torch.cuda.Event()
+                ev.record()
+            ev.synchronize()
+            lat.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        order = sorted(range(len(cands)), key=lat.__getitem__)
+        self.idle_latency_ms = [round(1e3 * lat[i], 3) for i in order]
+        return [cands[i] for i in order[:k]]
+
+    def fetch_host(self, ticket):
+        s = self.slots[ticket]
+        self.fetch(ticket)                                         # the replay has finished
+        if s.host is None:
+            s.host = tuple(torch.empty(o.shape, dtype=o.dtype, pin_memory=True) for o in s.outs)
+        if self._copy_stream is None:
+            self._copy_stream = self.idle_streams(1)[0]
+        with torch.cuda.stream(self._copy_stream):
+            for h, o in zip(s.host, s.outs):
+                h.copy_(o, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        ev.synchronize()
+        return s.host if len(s.host) > 1 else s.host[0]
 
     def drain(self):
         for k in range(self.depth):

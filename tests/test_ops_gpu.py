@@ -622,3 +622,79 @@ def test_x3d_ab_fused(dev, case, se):
     # the unfused pair of launches computes the same thing
     v = E.dwconv(E.conv(xc, pa), pb)
     _close(u.as_ncdhw(Cmid), v.as_ncdhw(Cmid).cpu(), 2e-5, "fused vs unfused")
+
+
+def _range_case(dev, scale_rows, M=512, K=192, N=96, seed=5):
+    from mspi_amd import engine as E
+    from mspi_amd.module import to_cl
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, K, generator=g)
+    x = x * torch.as_tensor(scale_rows(M))[:, None]
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    ref = x.double() @ w.double().t() + b.double()
+    xc = to_cl(x.t().reshape(1, K, 1, M, 1).to(dev))
+    pk = E.pack_conv(w, b, device=dev)
+    return E, x, ref, xc, pk
+
+
+def test_f16x3_overflow_is_reported_and_routed(dev):
+    """A row of |x| ~ 1e5 is beyond f16 (65504): the f16x3 kernels' hi half is inf.  (a) Untuned, the result is not finite and
+    the range guard says so (check_range raises) instead of inf flowing on silently; (b) on first sight while tuning, the
+    range check moves the layer to the fp32 MFMA path and the result is fp32-accurate against fp64."""
+    from mspi_amd._lib import MspiError
+    E, x, ref, xc, pk = _range_case(dev, lambda M: [1e5 if i == 7 else 1.0 for i in range(M)])
+    if pk.prec != E.PREC_F16X3:
+        pytest.skip("f16x3 only")
+    E.range_flag()
+    out = E.conv(xc, pk, tile=3).as_rows()
+    torch.cuda.synchronize()
+    assert not torch.isfinite(out[7]).all() and torch.isfinite(out[8]).all()
+    with pytest.raises(MspiError, match="f16x3 range"):
+        E.check_range()
+    assert not E.range_flag()                                # the check cleared it
+    E.autotune(True)
+    try:
+        out = E.conv(xc, pk).as_rows().cpu().double()
+    finally:
+        E.autotune(False)
+    assert pk.prec == E.PREC_F32 and E.RANGE_CHECK["moved"][-1][1] > 6e4
+    E.check_range()
+    assert ((out - ref).abs().max(1).values / ref.abs().max(1).values).max().item() < 2e-6
+
+
+def test_f16x3_tiny_tensor_is_routed(dev):
+    """Every row ~ 1e-6: the lo halves are f16 subnormals (absolute error 2^-25 per element), i.e. percent-level relative error
+    untuned; the range check (max|x| < 2^-5) moves the layer to fp32 and the result is fp32-accurate."""
+    E, x, ref, xc, pk = _range_case(dev, lambda M: [1e-6] * M)
+    if pk.prec != E.PREC_F16X3:
+        pytest.skip("f16x3 only")
+    untuned = E.conv(xc, pk, tile=3).as_rows().cpu().double()
+    err_untuned = (untuned - ref).abs().max().item()
+    E.autotune(True)
+    try:
+        out = E.conv(xc, pk).as_rows().cpu().double()
+    finally:
+        E.autotune(False)
+    assert pk.prec == E.PREC_F32
+    err = (out - ref).abs().max().item()
+    assert err < 1e-6 * ref.abs().max().item()               # fp32 rounding of the bias-dominated output
+    assert err_untuned < 2.0 ** -23 * 192 ** 0.5             # documented bound: 2^-25 per element x |w| ~ K^-1/2, K terms
+
+
+def test_f16x3_small_row_beside_normal_rows(dev):
+    """One row ~ 1e-6 among unit-scale rows: the tensor is in range, the layer stays f16x3, and the small row's ABSOLUTE error
+    is bounded by 2^-25 * sum|w| (negligible against every other row) -- its relative accuracy is what f16x3 gives up."""
+    E, x, ref, xc, pk = _range_case(dev, lambda M: [1e-6 if i == 3 else 1.0 for i in range(M)])
+    if pk.prec != E.PREC_F16X3:
+        pytest.skip("f16x3 only")
+    E.autotune(True)
+    try:
+        out = E.conv(xc, pk).as_rows().cpu().double()
+    finally:
+        E.autotune(False)
+    assert pk.prec == E.PREC_F16X3
+    err = (out - ref).abs()
+    assert err[3].max().item() < 2.0 ** -25 * 192 ** 0.5 * 4 + 1e-7     # lo-half subnormal error + fp32 rounding of bias + sum
+    others = torch.cat([err[:3], err[4:]])
+    assert (others.max(1).values / ref.abs().max(1).values[torch.arange(512) != 3]).max().item() < 2e-6

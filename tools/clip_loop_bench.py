@@ -4,7 +4,9 @@
 per-frame feature cache.  Synthetic frames already on the GPU; autotuned tiles; windows/s = uint8 maps produced per second."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")      # as mspi_amd.inference's entry does (runtime.configure_hw_queues)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+LAYOUTS = int(os.environ.get("CLB_LAYOUTS", "3"))
+ONLY_GRAPH = os.environ.get("CLB_ONLY_GRAPH") == "1"      # as mspi_amd.inference's entry does (runtime.configure_hw_queues)
 import torch
 from mspi_amd import engine as E, testing as T
 from mspi_amd.model.model_utils import AudioVisualSaliencyModel
@@ -27,8 +29,14 @@ OUT = (480, 640)
 
 def windows(first):
     idx = [list(range(first + b, first + b + 16)) for b in range(B)]
-    clips = torch.stack([video[i].permute(1, 0, 2, 3) for i in idx])
+    if os.environ.get("CLB_SLICES"):     # slices: no index tensor, i.e. no pageable H2D copy per window
+        clips = torch.stack([video[first + b: first + b + 16].permute(1, 0, 2, 3) for b in range(B)])
+    else:
+        clips = torch.stack([video[i].permute(1, 0, 2, 3) for i in idx])
     return clips, [j for w in idx for j in w]
+
+
+KEEP = {}
 
 
 def run(cached, graph):
@@ -36,7 +44,12 @@ def run(cached, graph):
     for step, first in enumerate(range(0, n_frames - 16 - B + 1, B)):
         if step == 3:                      # three warm-up batches (tuning, allocator, capture)
             torch.cuda.synchronize(); t0 = time.perf_counter(); n = 0
-        clips, flat = windows(first)
+        t_it = time.perf_counter()
+        if os.environ.get("CLB_BUILD") and step > 0 and graph:
+            clips, flat = KEEP["clips"], [j for b in range(B) for j in range(first + b, first + b + 16)]
+        else:
+            clips, flat = windows(first)
+            KEEP["clips"] = clips
         inputs = [clips, aud]
         if cached:
             while nxt <= flat[-1]:
@@ -48,20 +61,41 @@ def run(cached, graph):
             inputs += [torch.stack([feats[j][0] for j in flat]), torch.stack([feats[j][1] for j in flat])]
             for j in [j for j in feats if j < first + B]:
                 del feats[j]
-        fn = (lambda c, a, f1, f0, out=None: E.postprocess_u8(m(c, a, frame_feats=(f1, f0))[0], OUT, out=out)) if cached else \
-             (lambda c, a, out=None: E.postprocess_u8(m(c, a)[0], OUT, out=out))
+        fn = (lambda c, a, f1, f0: E.postprocess_u8(m(c, a, frame_feats=(f1, f0))[0], OUT)) if cached else \
+             (lambda c, a: E.postprocess_u8(m(c, a)[0], OUT))
         if graph:
             if pipe is None:
-                pipe = GraphPipeline(fn, inputs, depth=2, layouts=3, host_out=[((B,) + OUT, torch.uint8)])
-            t = pipe.submit(*inputs)
+                pipe = GraphPipeline(fn, inputs, depth=2, layouts=LAYOUTS)
+                idle = pipe.idle_streams(2)
+                pipe._copy_stream = idle[0]
+                if not os.environ.get("CLB_KEEP_STREAM"):
+                    idle[1].wait_stream(torch.cuda.current_stream())
+                    torch.cuda.set_stream(idle[1])                 # the loop's own launches move to a free hardware queue
+                print("    [idle-queue probe, ms]", pipe.idle_latency_ms, flush=True)
+            ta = time.perf_counter()
+            if os.environ.get("CLB_BUILD"):
+                def build(ins, first=first, extra=inputs[2:]):
+                    idx = [list(range(first + b, first + b + 16)) for b in range(B)]
+                    torch.stack([video[i].permute(1, 0, 2, 3) for i in idx], out=ins[0])
+                    for d_, s_ in zip(ins[2:], extra):
+                        d_.copy_(s_)
+                t = pipe.submit_build(build)
+            else:
+                t = pipe.submit(*inputs)
+            tb = time.perf_counter()
             if prev is not None:
-                out = pipe.fetch(prev).clone()       # the previous batch's maps come to the host while this one runs
+                pipe.fetch(prev)
+                tc = time.perf_counter()
+                out = pipe.fetch_host(prev).clone()  # the previous batch's maps come to the host while this one runs
+                if os.environ.get("CLB_DEBUG"):
+                    print("    step %2d: build %.1f ms, submit %.1f, wait for previous batch %.1f, D2H + clone %.1f" % (
+                        step, 1e3 * (ta - t_it), 1e3 * (tb - ta), 1e3 * (tc - tb), 1e3 * (time.perf_counter() - tc)), flush=True)
             prev = t
         else:
             out = fn(*inputs).cpu()
         n += B
     if graph:
-        out = pipe.fetch(prev).clone()
+        out = pipe.fetch_host(prev).clone()
     torch.cuda.synchronize()
     return n / (time.perf_counter() - t0), out
 
@@ -71,12 +105,13 @@ side = torch.cuda.Stream()      # the loop's own launches stay off the NULL stre
 with torch.cuda.stream(side):
     for cached in (False, True):
         for graph in (False, True):
-            res[cached, graph] = run(cached, graph)
+            res[cached, graph] = run(cached, graph) if (graph or not ONLY_GRAPH) else (0.0, None)
             torch.cuda.synchronize()
             torch.cuda.empty_cache()
 print("%s, batch %d, windows/s incl. post-processing and D2H of the uint8 maps:" % (name, B))
 print("  re-encoding every window : eager %.1f, hipGraph pipeline %.1f" % (res[False, False][0], res[False, True][0]))
 print("  per-frame feature cache  : eager %.1f, hipGraph pipeline %.1f" % (res[True, False][0], res[True, True][0]))
-print("  last batch, graph vs eager: %s; cache vs plain max |diff| %d grey levels" % (
-    "identical" if torch.equal(res[True, True][1], res[True, False][1]) and torch.equal(res[False, True][1], res[False, False][1]) else "DIFFERENT",
-    (res[True, True][1].int() - res[False, True][1].int()).abs().max().item()))
+if not ONLY_GRAPH:
+    print("  last batch, graph vs eager: %s; cache vs plain max |diff| %d grey levels" % (
+        "identical" if torch.equal(res[True, True][1], res[True, False][1]) and torch.equal(res[False, True][1], res[False, False][1]) else "DIFFERENT",
+        (res[True, True][1].int() - res[False, True][1].int()).abs().max().item()))

@@ -49,7 +49,7 @@ for M, K, N in SHAPES:
     d.To, d.Ho, d.Wo, d.Cout = 1, 1, M, N
     d.ldy, d.ldw, d.ldr, d.act, d.prec, d.w_scale = N, pk.ldw, 0, E.ACT_GELU, pk.prec, pk.w_scale
     res = {}
-    for t in [6, 7, 9, 10, 11, 12, 13, 14]:
+    for t in [6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18]:
         d.tile = t
         def run():
             _lib.check(lib.mspi_gemm_sp_fwd(C.byref(d), planes.data_ptr(), K, M * K, pk.w.data_ptr(), pk.bias.data_ptr(), None,
@@ -59,6 +59,7 @@ for M, K, N in SHAPES:
         except Exception as e:
             res[t] = None
     tb = min((v, k) for k, v in res.items() if v)
+    print("   per tile (us): " + "  ".join("%d:%s" % (k, "%.0f" % v if v else "-") for k, v in sorted(res.items())))
     d.tile = tb[1]
     run()
     err = (y - ref).abs().max().item()

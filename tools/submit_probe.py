@@ -2,7 +2,7 @@
 """Where does GraphPipeline.submit(*inputs) lose time against the resident-input form?  (x3dl, batch 8)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
 from mspi_amd import engine as E, testing as T
 from mspi_amd.model.model_utils import AudioVisualSaliencyModel
@@ -15,12 +15,13 @@ m = T.seeded(lambda: AudioVisualSaliencyModel(cfg), 0).to(dev)
 sys.stdout = so
 clips, aud = T.synth_inputs(8, 16, 224, 224, Wa=300, seed=1, device=dev)
 E.autotune(True); m(clips, aud); E.autotune(False)
-fn = lambda c, a, out=None: E.postprocess_u8(m(c, a)[0], (480, 640), out=out)
+fn = lambda c, a: E.postprocess_u8(m(c, a)[0], (480, 640))
 N = 24
 
 
 def loop(pipe, mode, host):
     prev = None
+    tf = 0.0
     torch.cuda.synchronize(); t0 = time.perf_counter(); th = 0.0
     for i in range(N):
         a = time.perf_counter()
@@ -34,19 +35,26 @@ def loop(pipe, mode, host):
             t = pipe.submit(c2, a2)
         th += time.perf_counter() - a
         if prev is not None:
-            o = pipe.fetch(prev)
+            a = time.perf_counter()
             if host:
-                o = o.clone()
+                pipe.fetch(prev)
+                b = time.perf_counter()
+                o = pipe.fetch_host(prev)
+                tf += time.perf_counter() - b
+            else:
+                pipe.fetch(prev)
         prev = t
     pipe.fetch(prev)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    if host:
+        print("      (D2H part of fetch_host: %.2f ms per batch; idle-queue probe %s)" % (1e3 * tf / N, getattr(pipe, "idle_latency_ms", None)))
     return 8 * N / el, 1e3 * th / N
 
 
 side = torch.cuda.Stream()
 for host in (False, True):
-    pipe = GraphPipeline(fn, (clips, aud), depth=2, layouts=3, host_out=[((8, 480, 640), torch.uint8)] if host else None)
+    pipe = GraphPipeline(fn, (clips, aud), depth=2, layouts=3)
     for stream_name, ctx in (("null stream", None), ("side stream", side)):
         for mode in ("resident", "same", "fresh"):
             if ctx is None:
