@@ -381,23 +381,32 @@ def main():
     lat_main = round(pipe.latency_ms(), 4) if pipe else None
     layout_main = pipe.layout if pipe else None
     if pipe and not args.no_postproc:
-        # the forward-only pipeline is released first: which hardware queue a stream lands on follows creation order, and a
-        # second pipeline beside the first would share queues with it (measured: +6 ms latency from lost branch overlap)
-        pipe.after = None
-        outs = [o.clone() for o in outs]
-        pipe = None
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
-        pipe_pp = GraphPipeline(lambda c, a: E.postprocess_u8(model(c, a)[0], (480, 640)), (clips, audio), depth=args.inflight,
-                                layouts=args.stream_layouts, log=log)
-        counter[0] = 0
-        el_pp = timed(pipe_pp.submit, lambda: None)
-        u8 = pipe_pp.fetch(0)
-        if not (u8.dtype == torch.uint8 and tuple(u8.shape) == (B, 480, 640) and int(u8.max()) == 255 and int(u8.min()) == 0):
+        # the SAME pipeline (same graphs, same streams, same hardware queues) with the four post-process launches issued on
+        # each replay's own stream right behind it: a second pipeline lands on other queues and measures the layout, not the
+        # kernels (seen: +1.1 ms latency for 0.13 ms of kernels)
+        prev_after = pipe.after
+        u8 = [None] * depth
+
+        def with_postproc(k, o):
+            if prev_after is not None:
+                prev_after(k, o)
+            u8[k] = E.postprocess_u8(o[0], (480, 640))
+
+        pipe.after = with_postproc
+        el_pp = timed(step, flush)
+        lat = []
+        for _ in range(7):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            pipe.fetch(pipe.submit())
+            lat.append(time.perf_counter() - t1)
+        pipe.after = prev_after
+        if not all(u is not None and u.dtype == torch.uint8 and tuple(u.shape) == (B, 480, 640) and int(u.max()) == 255
+                   and int(u.min()) == 0 for u in u8):
             raise SystemExit("bench: post-processed maps are not min-max normalised uint8 images")
         pp = {"ms_per_clip_with_postproc": round(1e3 * el_pp / args.steps / B, 4),
-              "latency_ms_per_batch_with_postproc": round(pipe_pp.latency_ms(), 4)}
-        del pipe_pp, u8
+              "latency_ms_per_batch_with_postproc": round(1e3 * sorted(lat)[len(lat) // 2], 4)}
+        del u8
     graph_mode = not args.no_graph
 
     if rank != 0:

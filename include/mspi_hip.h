@@ -189,6 +189,14 @@ typedef struct MspiAttnDesc {
 int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float* k, const float* v, const float* res,
                   const float* biasT, const float* maskT, const int32_t* tok_idx, float* o, mspi_stream_t stream);
 
+/* The same attention (f16x3 only) with K and V split ONCE per (sequence, head) into f16 hi/lo planes in a caller-owned
+ * workspace of mspi_attn_ws_bytes(d) bytes, instead of by every query tile of that head on its own copy: two launches (plane
+ * kernel, attention kernel), results bit-identical to mspi_attn_fwd.  mspi_attn_ws_bytes returns 0 for other precisions. */
+size_t mspi_attn_ws_bytes(const MspiAttnDesc* d);
+int mspi_attn_fwd_ws(const MspiAttnDesc* d, const float* q, const float* k, const float* v, const float* res,
+                     const float* biasT, const float* maskT, const int32_t* tok_idx, float* o, void* workspace,
+                     mspi_stream_t stream);
+
 /* MViTv2 decomposed relative positions folded into the attention contraction (backbones/MViT.py:905-997):
  *   qa[b,h,i,:] = [ scale*q_i | q_i.Rh[hq(i),0..kH) | q_i.Rw[wq(i),0..kW) | q_i.Rt[tq(i),0..kT) | 0 ]   (DA columns)
  *   ka[b,h,j,:] = [ k_j | onehot_kH(hk(j)) | onehot_kW(wk(j)) | onehot_kT(tk(j)) | 0 ]

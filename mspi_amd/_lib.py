@@ -114,6 +114,8 @@ _SIGNATURES = {
     "mspi_layernorm_fwd": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P, _P, C.c_float, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mspi_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mspi_attn_ws_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),
+    "mspi_attn_fwd_ws": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mspi_space_to_depth": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mspi_mvit_qk_augment": (C.c_int, [C.POINTER(MvitAugDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "mspi_mvit_qk_augment_p": (C.c_int, [C.POINTER(MvitAugDesc), _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P]),

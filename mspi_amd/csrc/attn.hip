@@ -32,6 +32,11 @@ struct AttnArgs {
   long q_sB, q_sH, q_sT, k_sB, k_sH, k_sT, v_sB, v_sH, v_sT, o_sB, o_sH, o_sT;
   float scale;
   int single;
+  // pre-split K / V^T planes (attn_kv_planes_kernel): Kp [seq*head][2][Nkp][D], Vp [seq*head][2][DV][Nkp] halves, Nkp = Nk
+  // rounded up to 32, already scaled by KSC / VSC, zero beyond Nk
+  _Float16* kp;
+  _Float16* vp;
+  int Nkp;
 };
 
 // D = head dim of Q/K (the contraction of S), DV = head dim of V / O.  They differ for MViT, whose decomposed
@@ -204,7 +209,61 @@ __device__ __forceinline__ void split4(const float4 v, v4h& hi, v4h& lo) {
   }
 }
 
+constexpr float ATT_KSC = 16.f, ATT_VSC = 16.f;
+
+// K and V of every (sequence, head) split ONCE into the f16 hi/lo planes the attention kernel stages: every query tile of
+// that head (196 workgroups at Nq = 25088) used to redo this split on its own copy -- ~200 VALU instructions per thread and
+// 32-key step, beside ~60 MFMAs.  One workgroup per 32-key tile; same arithmetic as the in-kernel staging, so the planes
+// hold bit for bit what attn_f16x3_kernel<.., false> puts into LDS.
 template <int D, int DV>
+__global__ __launch_bounds__(256) void attn_kv_planes_kernel(const AttnArgs p) {
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y / p.Hh, h = blockIdx.y % p.Hh;
+  const int k0 = blockIdx.x * 32;
+  const int sample = p.tok_idx ? b / p.nwin : b;
+  const int* tix = p.tok_idx ? p.tok_idx + (long)(b % p.nwin) * p.Nk : nullptr;
+  const float* kb = p.k + (long)sample * p.k_sB + (long)h * p.k_sH;
+  const float* vb = p.v + (long)sample * p.v_sB + (long)h * p.v_sH;
+  _Float16* Kh = p.kp + (long)blockIdx.y * 2 * p.Nkp * D;
+  _Float16* Kl = Kh + (long)p.Nkp * D;
+  _Float16* Vh = p.vp + (long)blockIdx.y * 2 * DV * p.Nkp;
+  _Float16* Vl = Vh + (long)DV * p.Nkp;
+  for (int idx = tid; idx < 32 * (D / 4); idx += 256) {
+    const int row = idx / (D / 4), c4 = idx - row * (D / 4);
+    const bool ok = k0 + row < p.Nk;
+    const int kr = ok ? (tix ? tix[k0 + row] : k0 + row) : 0;
+    float4 kv = *reinterpret_cast<const float4*>(kb + (long)kr * p.k_sT + c4 * 4);
+    kv = ok ? make_float4(kv.x * ATT_KSC, kv.y * ATT_KSC, kv.z * ATT_KSC, kv.w * ATT_KSC) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v4h hi, lo;
+    split4(kv, hi, lo);
+    *reinterpret_cast<v4h*>(&Kh[(long)(k0 + row) * D + c4 * 4]) = hi;
+    *reinterpret_cast<v4h*>(&Kl[(long)(k0 + row) * D + c4 * 4]) = lo;
+  }
+  for (int idx = tid; idx < 16 * (DV / 4); idx += 256) {
+    const int kp = idx & 15, c4 = idx >> 4;
+    const bool ok0 = k0 + 2 * kp < p.Nk, ok1 = k0 + 2 * kp + 1 < p.Nk;
+    const int r0 = ok0 ? (tix ? tix[k0 + 2 * kp] : k0 + 2 * kp) : 0;
+    const int r1 = ok1 ? (tix ? tix[k0 + 2 * kp + 1] : k0 + 2 * kp + 1) : 0;
+    float4 v0 = *reinterpret_cast<const float4*>(vb + (long)r0 * p.v_sT + c4 * 4);
+    float4 v1 = *reinterpret_cast<const float4*>(vb + (long)r1 * p.v_sT + c4 * 4);
+    v0 = ok0 ? make_float4(v0.x * ATT_VSC, v0.y * ATT_VSC, v0.z * ATT_VSC, v0.w * ATT_VSC) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v1 = ok1 ? make_float4(v1.x * ATT_VSC, v1.y * ATT_VSC, v1.z * ATT_VSC, v1.w * ATT_VSC) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v4h h0, l0, h1, l1;
+    split4(v0, h0, l0);
+    split4(v1, h1, l1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+      v2h ph, pl;
+      ph[0] = h0[j]; ph[1] = h1[j];
+      pl[0] = l0[j]; pl[1] = l1[j];
+      *reinterpret_cast<v2h*>(&Vh[(long)(c4 * 4 + j) * p.Nkp + k0 + 2 * kp]) = ph;
+      *reinterpret_cast<v2h*>(&Vl[(long)(c4 * 4 + j) * p.Nkp + k0 + 2 * kp]) = pl;
+    }
+  }
+}
+
+template <int D, int DV, bool PL = false>
 __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
   constexpr int KP = D + 8;     // K plane row pitch (halves)
   constexpr int VP = 36;        // Vt plane row pitch (halves): 32 keys + 4
@@ -213,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
   // Power-of-two operand scales (exact; undone on the fp32 side).  The lo half of a split value is ~2^-12 of it, and
   // f16 loses precision below 2^-14 (subnormals; the matrix pipe may flush them): q*scale ~ 0.1 and p <= 1 would keep
   // only their hi halves.  Scaled, every operand of ordinary magnitude has a NORMAL lo half.
-  constexpr float QSC = 64.f, KSC = 16.f, PSC = 1024.f, VSC = 16.f;
+  constexpr float QSC = 64.f, KSC = ATT_KSC, PSC = 1024.f, VSC = ATT_VSC;
   __shared__ __attribute__((aligned(16))) _Float16 smem[2 * 32 * KP + 2 * DV * VP];
   _Float16* Kh = smem;
   _Float16* Kl = smem + 32 * KP;
@@ -261,8 +320,32 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
 
   for (int k0 = 0; k0 < p.Nk; k0 += 32) {
     __syncthreads();  // previous tile fully consumed
+    if (PL) {
+      // planes made by attn_kv_planes_kernel: staging is a copy -- 16 B per K chunk, 8 + 8 B per V^T chunk (its LDS rows are
+      // 72 B apart), no conversion work
+      const _Float16* gKh = p.kp + (long)blockIdx.y * 2 * p.Nkp * D + (long)k0 * D;
+      const _Float16* gKl = gKh + (long)p.Nkp * D;
+      for (int idx = tid; idx < 32 * (D / 8); idx += 256) {
+        const int row = idx / (D / 8), c = idx - row * (D / 8);
+        const uint4 a = *reinterpret_cast<const uint4*>(gKh + row * D + 8 * c);
+        const uint4 bq = *reinterpret_cast<const uint4*>(gKl + row * D + 8 * c);
+        *reinterpret_cast<uint4*>(&Kh[row * KP + 8 * c]) = a;
+        *reinterpret_cast<uint4*>(&Kl[row * KP + 8 * c]) = bq;
+      }
+      const _Float16* gVh = p.vp + (long)blockIdx.y * 2 * DV * p.Nkp + k0;
+      const _Float16* gVl = gVh + (long)DV * p.Nkp;
+      for (int idx = tid; idx < DV * 4; idx += 256) {
+        const int d = idx >> 2, c = idx & 3;
+        const uint4 a = *reinterpret_cast<const uint4*>(gVh + (long)d * p.Nkp + 8 * c);
+        const uint4 bq = *reinterpret_cast<const uint4*>(gVl + (long)d * p.Nkp + 8 * c);
+        *reinterpret_cast<uint2*>(&Vh[d * VP + 8 * c]) = make_uint2(a.x, a.y);
+        *reinterpret_cast<uint2*>(&Vh[d * VP + 8 * c + 4]) = make_uint2(a.z, a.w);
+        *reinterpret_cast<uint2*>(&Vl[d * VP + 8 * c]) = make_uint2(bq.x, bq.y);
+        *reinterpret_cast<uint2*>(&Vl[d * VP + 8 * c + 4]) = make_uint2(bq.z, bq.w);
+      }
+    }
     // K: thread -> (key row, 4 d): two 8-B plane writes
-    for (int idx = tid; idx < 32 * (D / 4); idx += 256) {
+    for (int idx = tid; !PL && idx < 32 * (D / 4); idx += 256) {
       const int row = idx / (D / 4), c4 = idx - row * (D / 4);
       const bool ok = k0 + row < p.Nk;
       const int kr = ok ? (tix ? tix[k0 + row] : k0 + row) : 0;
@@ -274,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
       *reinterpret_cast<v4h*>(&Kl[row * KP + c4 * 4]) = lo;
     }
     // V, transposed: thread -> (key pair fastest, 4 d): 4-B writes Vt[d][2kp .. 2kp+1]
-    for (int idx = tid; idx < 16 * (DV / 4); idx += 256) {
+    for (int idx = tid; !PL && idx < 16 * (DV / 4); idx += 256) {
       const int kp = idx & 15, c4 = idx >> 4;
       const bool ok0 = k0 + 2 * kp < p.Nk, ok1 = k0 + 2 * kp + 1 < p.Nk;
       const int r0 = ok0 ? (tix ? tix[k0 + 2 * kp] : k0 + 2 * kp) : 0;
@@ -578,9 +661,33 @@ extern "C" int mspi_mvit_qk_augment(const MspiMvitAugDesc* d, const float* q, co
   return check_launch("mspi_mvit_qk_augment");
 }
 
+static long attn_nkp(const MspiAttnDesc* d) { return ((long)d->Nk + 31) / 32 * 32; }
+
+extern "C" size_t mspi_attn_ws_bytes(const MspiAttnDesc* d) {
+  if (!d || d->prec != MSPI_PREC_F16X3 || d->B <= 0 || d->Hh <= 0 || d->Nk <= 0) return 0;
+  return (size_t)d->B * d->Hh * 2 * attn_nkp(d) * (size_t)(d->D + d->Dv) * sizeof(_Float16);
+}
+
+static int attn_fwd_impl(const MspiAttnDesc* d, const float* q, const float* k, const float* v, const float* res,
+                         const float* biasT, const float* maskT, const int32_t* tok_idx, float* o, void* ws,
+                         mspi_stream_t stream);
+
 extern "C" int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float* k, const float* v, const float* res,
                              const float* biasT, const float* maskT, const int32_t* tok_idx, float* o,
                              mspi_stream_t stream) {
+  return attn_fwd_impl(d, q, k, v, res, biasT, maskT, tok_idx, o, nullptr, stream);
+}
+
+extern "C" int mspi_attn_fwd_ws(const MspiAttnDesc* d, const float* q, const float* k, const float* v, const float* res,
+                                const float* biasT, const float* maskT, const int32_t* tok_idx, float* o, void* workspace,
+                                mspi_stream_t stream) {
+  MSPI_REQUIRE(workspace && aligned16(workspace), "mspi_attn_fwd_ws: workspace must be a 16-B aligned device buffer");
+  return attn_fwd_impl(d, q, k, v, res, biasT, maskT, tok_idx, o, workspace, stream);
+}
+
+static int attn_fwd_impl(const MspiAttnDesc* d, const float* q, const float* k, const float* v, const float* res,
+                         const float* biasT, const float* maskT, const int32_t* tok_idx, float* o, void* ws,
+                         mspi_stream_t stream) {
   MSPI_REQUIRE(d && q && k && v && o, "mspi_attn_fwd: null argument");
   MSPI_REQUIRE(d->B > 0 && d->Hh > 0 && d->Nq > 0 && d->Nk > 0, "mspi_attn_fwd: empty extent");
   const int64_t st[12] = {d->q_sB, d->q_sH, d->q_sT, d->k_sB, d->k_sH, d->k_sT, d->v_sB, d->v_sH, d->v_sT, d->o_sB, d->o_sH, d->o_sT};
@@ -596,6 +703,7 @@ extern "C" int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float*
   a.B = d->B; a.Hh = d->Hh; a.Nq = d->Nq; a.Nk = d->Nk; a.nmask = d->nmask > 0 ? d->nmask : 1;
   a.nwin = d->nwin > 0 ? d->nwin : 1;
   a.single = single_product();
+  a.kp = a.vp = nullptr; a.Nkp = 0;
   a.q_sB = d->q_sB; a.q_sH = d->q_sH; a.q_sT = d->q_sT;
   a.k_sB = d->k_sB; a.k_sH = d->k_sH; a.k_sT = d->k_sT;
   a.v_sB = d->v_sB; a.v_sH = d->v_sH; a.v_sT = d->v_sT;
@@ -604,6 +712,25 @@ extern "C" int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float*
   dim3 grid((unsigned)((d->Nq + 127) / 128), (unsigned)(d->B * d->Hh));
   hipStream_t s = (hipStream_t)stream;
   const int key = d->D * 1000 + d->Dv;
+  if (d->prec == MSPI_PREC_F16X3 && ws) {
+    a.Nkp = (int)attn_nkp(d);
+    a.kp = reinterpret_cast<_Float16*>(ws);
+    a.vp = a.kp + (size_t)d->B * d->Hh * 2 * a.Nkp * d->D;
+    dim3 pgrid((unsigned)(a.Nkp / 32), (unsigned)(d->B * d->Hh));
+#define MSPI_ATTN_PL(DD, DVV)                                                                        \
+  case DD * 1000 + DVV:                                                                              \
+    hipLaunchKernelGGL((attn_kv_planes_kernel<DD, DVV>), pgrid, dim3(256), 0, s, a);                 \
+    hipLaunchKernelGGL((attn_f16x3_kernel<DD, DVV, true>), grid, dim3(256), 0, s, a);                \
+    break;
+    switch (key) {
+      MSPI_ATTN_PL(32, 32) MSPI_ATTN_PL(64, 64) MSPI_ATTN_PL(96, 96) MSPI_ATTN_PL(128, 128) MSPI_ATTN_PL(128, 96) MSPI_ATTN_PL(160, 96)
+      default:
+        set_error("mspi_attn_fwd_ws: (D=%d, Dv=%d) not in {(32,32),(64,64),(96,96),(128,128),(128,96),(160,96)}", d->D, d->Dv);
+        return MSPI_EINVAL;
+    }
+#undef MSPI_ATTN_PL
+    return check_launch("mspi_attn_fwd_ws");
+  }
   if (d->prec == MSPI_PREC_F16X3) {
     switch (key) {
       case 32032: hipLaunchKernelGGL((attn_f16x3_kernel<32, 32>), grid, dim3(256), 0, s, a); break;

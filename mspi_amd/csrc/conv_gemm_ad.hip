@@ -38,7 +38,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
   static_assert(BN % 32 == 0 && BN >= 32 && BN <= 256, "BN: multiple of 32, <= 256");
   // Ring depth: 3 stages (two K steps of DMA in flight behind a COUNTED vmcnt + raw s_barrier, so the barrier does
   // not drain the newest stage) where 3 stages still leave two workgroups per CU, else 2 stages.
-  constexpr int NST = 2;   // measured: a 3-deep ring (BN <= 64) loses a resident workgroup to LDS and is 15-25 % slower
+#ifndef MSPI_DMA_NST_SP
+#define MSPI_DMA_NST_SP 2
+#endif
+  // measured: a 3-deep ring (BN <= 64) loses a resident workgroup to LDS and is 15-25 % slower (fp32-A form, round 1);
+  // -DMSPI_DMA_NST_SP=3 builds the pre-split 128 x 64 form with a 3-deep ring for an A/B (tools/sp_probe.py, MSPI_LIB_PATH)
+  constexpr int NST = (APRE && BN == 64 && NW == 4) ? MSPI_DMA_NST_SP : 2;
   constexpr int DMA_PER_STAGE = 4 + 2 * HBI;    // upper bound of this thread's DMA instructions per stage
   __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
 

@@ -844,11 +844,22 @@ def attention(qkv, B, Ntok, heads, hd, scale, out=None, biasT=None, maskT=None, 
     d.scale, d.prec = float(scale), DEFAULT_PREC
     base = qkv.ptr
     with _Timed("attention", 4.0 * B * heads * Ntok * Ntok * hd, 16.0 * B * Ntok * Cc, "B=%d h=%d N=%d d=%d" % (B, heads, Ntok, hd)):
-        check(lib.mspi_attn_fwd(C.byref(d), base, base + 4 * Cc, base + 8 * Cc, None,
-                                biasT.data_ptr() if biasT is not None else None,
-                                maskT.data_ptr() if maskT is not None else None,
-                                tok_idx.data_ptr() if tok_idx is not None else None, out.ptr, _stream()), "mspi_attn_fwd")
+        _attn_launch(lib, d, base, base + 4 * Cc, base + 8 * Cc, None,
+                     biasT.data_ptr() if biasT is not None else None, maskT.data_ptr() if maskT is not None else None,
+                     tok_idx.data_ptr() if tok_idx is not None else None, out.ptr, qkv.buf.device)
     return out
+
+
+ATTN_PLANES = _os.environ.get("MSPI_ATTN_PLANES", "1") != "0"      # A/B switch: K / V split once per head (mspi_attn_fwd_ws)
+
+
+def _attn_launch(lib, d, q, k, v, res, biasT, maskT, tok_idx, o, dev):
+    nbytes = lib.mspi_attn_ws_bytes(C.byref(d)) if ATTN_PLANES else 0
+    if nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # stream-ordered: safe to drop after the launch
+        check(lib.mspi_attn_fwd_ws(C.byref(d), q, k, v, res, biasT, maskT, tok_idx, o, ws.data_ptr(), _stream()), "mspi_attn_fwd_ws")
+    else:
+        check(lib.mspi_attn_fwd(C.byref(d), q, k, v, res, biasT, maskT, tok_idx, o, _stream()), "mspi_attn_fwd")
 
 
 def mlp(x, pk, res=None, ln=None, eps=1e-6, out=None):
@@ -959,8 +970,7 @@ def mvit_attention(q, k, v, B, heads, hd, scale, q_thw, k_thw, Rh, Rw, Rt, out=N
     assert q.ld == out.ld and q.dense and out.dense   # residual pooling reads q with o's strides
     with _Timed("attention", 2.0 * B * heads * Nq * Nk * (DA + hd), 4.0 * B * heads * (Nq * (DA + 2 * hd) + Nk * (DA + hd)),
                 "B=%d h=%d Nq=%d Nk=%d d=%d+%d" % (B, heads, Nq, Nk, DA, hd)):
-        check(lib.mspi_attn_fwd(C.byref(d), qa.data_ptr(), ka.data_ptr(), v.ptr, q.ptr, None, None, None, out.ptr,
-                                _stream()), "mspi_attn_fwd")
+        _attn_launch(lib, d, qa.data_ptr(), ka.data_ptr(), v.ptr, q.ptr, None, None, None, out.ptr, dev)
     return out
 
 

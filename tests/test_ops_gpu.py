@@ -698,3 +698,27 @@ def test_f16x3_small_row_beside_normal_rows(dev):
     assert err[3].max().item() < 2.0 ** -25 * 192 ** 0.5 * 4 + 1e-7     # lo-half subnormal error + fp32 rounding of bias + sum
     others = torch.cat([err[:3], err[4:]])
     assert (others.max(1).values / ref.abs().max(1).values[torch.arange(512) != 3]).max().item() < 2e-6
+
+
+@pytest.mark.parametrize("B,H,N,D,win", [(2, 2, 100, 64, False), (3, 4, 392, 32, True), (1, 1, 450, 96, False)])
+def test_attention_planes_bit_identical(dev, B, H, N, D, win):
+    """mspi_attn_fwd_ws (K / V split once per head into workspace planes, staged by plain copies) == mspi_attn_fwd (every
+    query tile splits its own copy), bit for bit -- ragged key counts, several heads, a windowed token index."""
+    from mspi_amd import engine as E
+    if E.DEFAULT_PREC != E.PREC_F16X3:
+        pytest.skip("f16x3 only")
+    g = torch.Generator().manual_seed(N + D)
+    nwin = 2 if win else 1
+    qkv = torch.randn(B * nwin * N, 3 * H * D, generator=g)
+    x = E.CL(qkv.to(dev).view(-1), 0, B, 1, 1, nwin * N, 3 * H * D, 3 * H * D)
+    tok = None
+    if win:
+        tok = torch.randperm(nwin * N, generator=g).view(nwin, N).to(torch.int32).to(dev)     # the windows partition the tokens
+    outs = []
+    for planes in (True, False):
+        E.ATTN_PLANES = planes
+        try:
+            outs.append(E.attention(x, B * nwin, N, H, D, D ** -0.5, tok_idx=tok).buf.clone())
+        finally:
+            E.ATTN_PLANES = True
+    assert torch.equal(outs[0], outs[1])

@@ -2,7 +2,7 @@
 # Round profile on the GPU box: bench line, rocprofv3 kernel trace of the same command, HBM counter passes.
 # usage: tools/profile_round.sh <tag>      (writes gpurun_out/prof_<tag>/...)
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -21,5 +21,11 @@ rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o r --output-format csv -- python3
 echo "write done"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_mfma -o r --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-graph --tune-cache $CACHE --no-cpu-baseline --no-roofline > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err
 echo "mfma done"
+python3 profiles/summarize.py $OUT $TAG > $OUT/summary.log 2>&1 || true
+python3 tools/mfma_busy_summary.py $OUT/pmc_mfma "x3dl+audio B=8 (bench.py --no-graph)" > profiles/${TAG}_mfma_busy.csv || true
+cp $OUT/bench.json profiles/${TAG}_bench.json; cp $OUT/bench_under_rocprof.json profiles/${TAG}_bench_under_rocprof.json
+cp $OUT/bench_under_rocprof_serial.json profiles/${TAG}_bench_under_rocprof_streams0.json
+for d in trace trace_serial; do f=$(find $OUT/$d -name "*_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f profiles/${TAG}_rocprofv3_kernel_stats$([ $d = trace_serial ] && echo _streams0).csv; done
+mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
 # keep only the small summaries (the raw traces are tens of MB)
 find $OUT -name "*_kernel_trace.csv" -delete
