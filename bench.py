@@ -420,8 +420,8 @@ def main():
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "ms_per_clip": round(1e3 * elapsed / args.steps / B, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if E.DEFAULT_PREC == E.PREC_F32 else
-                 ("f32 storage/accumulate; GEMMs on plain f16 operands (MSPI_F16_PRODUCTS=1: measurement mode, fails the 1e-3 parity bar)"
-                  if os.environ.get("MSPI_F16_PRODUCTS") == "1" else
+                 ("f32 storage/accumulate; GEMMs on plain f16 operands (libmspi_hip_single.so: measurement build, fails the 1e-3 parity bar)"
+                  if "single" in os.path.basename(os.environ.get("MSPI_LIB_PATH", "")) else
                   "f32 storage/accumulate; GEMMs as f16x3 split products on the f16 MFMA pipe"),
         "data": "synthetic",
         "config": {"workload": "%s motion encoder + ConvNeXt-T + ResNet18 audio + SyncBlock + decoder (AudioVisualSaliencyModel "

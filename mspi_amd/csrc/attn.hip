@@ -31,8 +31,6 @@ struct AttnArgs {
   int B, Hh, Nq, Nk, nmask, nwin;
   long q_sB, q_sH, q_sT, k_sB, k_sH, k_sT, v_sB, v_sH, v_sT, o_sB, o_sH, o_sT;
   float scale;
-  int single;
-  // pre-split K / V^T planes (attn_kv_planes_kernel): Kp [seq*head][2][Nkp][D], Vp [seq*head][2][DV][Nkp] halves, Nkp = Nk
   // rounded up to 32, already scaled by KSC / VSC, zero beyond Nk
   _Float16* kp;
   _Float16* vp;
@@ -263,7 +261,7 @@ __global__ __launch_bounds__(256) void attn_kv_planes_kernel(const AttnArgs p) {
   }
 }
 
-template <int D, int DV, bool PL = false>
+template <int D, int DV, bool PL = false, bool PF = false>
 __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
   constexpr int KP = D + 8;     // K plane row pitch (halves)
   constexpr int VP = 36;        // Vt plane row pitch (halves): 32 keys + 4
@@ -318,30 +316,58 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
   const float* kb = p.k + (long)sample * p.k_sB + (long)h * p.k_sH;
   const float* vb = p.v + (long)sample * p.v_sB + (long)h * p.v_sH;
 
+  constexpr int PFK = PL ? (32 * (D / 8) + 255) / 256 : 1, PFV = PL ? (DV * 4 + 255) / 256 : 1;
+  uint4 pf_kh[PFK], pf_kl[PFK], pf_vh[PFV], pf_vl[PFV];
+  auto prefetch = [&](int k0) {
+    if (!PL) return;
+    const _Float16* gKh = p.kp + (long)blockIdx.y * 2 * p.Nkp * D + (long)k0 * D;
+    const _Float16* gKl = gKh + (long)p.Nkp * D;
+    const _Float16* gVh = p.vp + (long)blockIdx.y * 2 * DV * p.Nkp + k0;
+    const _Float16* gVl = gVh + (long)DV * p.Nkp;
+#pragma unroll
+    for (int i = 0; i < PFK; ++i) {
+      const int idx = tid + 256 * i;
+      const int ii = idx < 32 * (D / 8) ? idx : 0;            // a K tile is one contiguous run of 32 * D halves per plane
+      pf_kh[i] = *reinterpret_cast<const uint4*>(gKh + 8 * ii);
+      pf_kl[i] = *reinterpret_cast<const uint4*>(gKl + 8 * ii);
+    }
+#pragma unroll
+    for (int i = 0; i < PFV; ++i) {
+      const int idx = tid + 256 * i;
+      const int ii = idx < DV * 4 ? idx : 0;
+      const int d = ii >> 2, c = ii & 3;
+      pf_vh[i] = *reinterpret_cast<const uint4*>(gVh + (long)d * p.Nkp + 8 * c);
+      pf_vl[i] = *reinterpret_cast<const uint4*>(gVl + (long)d * p.Nkp + 8 * c);
+    }
+  };
+  if (PF) prefetch(0);
+
   for (int k0 = 0; k0 < p.Nk; k0 += 32) {
     __syncthreads();  // previous tile fully consumed
+    if (PL && !PF) prefetch(k0);
     if (PL) {
       // planes made by attn_kv_planes_kernel: staging is a copy -- 16 B per K chunk, 8 + 8 B per V^T chunk (its LDS rows are
-      // 72 B apart), no conversion work
-      const _Float16* gKh = p.kp + (long)blockIdx.y * 2 * p.Nkp * D + (long)k0 * D;
-      const _Float16* gKl = gKh + (long)p.Nkp * D;
-      for (int idx = tid; idx < 32 * (D / 8); idx += 256) {
-        const int row = idx / (D / 8), c = idx - row * (D / 8);
-        const uint4 a = *reinterpret_cast<const uint4*>(gKh + row * D + 8 * c);
-        const uint4 bq = *reinterpret_cast<const uint4*>(gKl + row * D + 8 * c);
-        *reinterpret_cast<uint4*>(&Kh[row * KP + 8 * c]) = a;
-        *reinterpret_cast<uint4*>(&Kl[row * KP + 8 * c]) = bq;
+      // 72 B apart), no conversion work.  The chunks of this tile were fetched into registers while the previous tile was
+      // being computed (pf_*), so the only exposed global latency is the first tile's.
+#pragma unroll
+      for (int i = 0; i < PFK; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < 32 * (D / 8)) {
+          const int row = idx / (D / 8), c = idx - row * (D / 8);
+          *reinterpret_cast<uint4*>(&Kh[row * KP + 8 * c]) = pf_kh[i];
+          *reinterpret_cast<uint4*>(&Kl[row * KP + 8 * c]) = pf_kl[i];
+        }
       }
-      const _Float16* gVh = p.vp + (long)blockIdx.y * 2 * DV * p.Nkp + k0;
-      const _Float16* gVl = gVh + (long)DV * p.Nkp;
-      for (int idx = tid; idx < DV * 4; idx += 256) {
-        const int d = idx >> 2, c = idx & 3;
-        const uint4 a = *reinterpret_cast<const uint4*>(gVh + (long)d * p.Nkp + 8 * c);
-        const uint4 bq = *reinterpret_cast<const uint4*>(gVl + (long)d * p.Nkp + 8 * c);
-        *reinterpret_cast<uint2*>(&Vh[d * VP + 8 * c]) = make_uint2(a.x, a.y);
-        *reinterpret_cast<uint2*>(&Vh[d * VP + 8 * c + 4]) = make_uint2(a.z, a.w);
-        *reinterpret_cast<uint2*>(&Vl[d * VP + 8 * c]) = make_uint2(bq.x, bq.y);
-        *reinterpret_cast<uint2*>(&Vl[d * VP + 8 * c + 4]) = make_uint2(bq.z, bq.w);
+#pragma unroll
+      for (int i = 0; i < PFV; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < DV * 4) {
+          const int d = idx >> 2, c = idx & 3;
+          *reinterpret_cast<uint2*>(&Vh[d * VP + 8 * c]) = make_uint2(pf_vh[i].x, pf_vh[i].y);
+          *reinterpret_cast<uint2*>(&Vh[d * VP + 8 * c + 4]) = make_uint2(pf_vh[i].z, pf_vh[i].w);
+          *reinterpret_cast<uint2*>(&Vl[d * VP + 8 * c]) = make_uint2(pf_vl[i].x, pf_vl[i].y);
+          *reinterpret_cast<uint2*>(&Vl[d * VP + 8 * c + 4]) = make_uint2(pf_vl[i].z, pf_vl[i].w);
+        }
       }
     }
     // K: thread -> (key row, 4 d): two 8-B plane writes
@@ -380,6 +406,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
       }
     }
     __syncthreads();
+    if (PL && PF && k0 + 32 < p.Nk) prefetch(k0 + 32);      // in flight under this tile's MFMAs and softmax
 
     // S^T = K . Q^T
     v16f s;
@@ -389,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
     for (int st = 0; st < NS; ++st) {
       const v8h kh = *reinterpret_cast<const v8h*>(&Kh[li * KP + 16 * st + 8 * lh]);
       const v8h kl = *reinterpret_cast<const v8h*>(&Kl[li * KP + 16 * st + 8 * lh]);
-      if (!p.single) {
+      if (!kSingleProduct) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], s, 0, 0, 0);
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], s, 0, 0, 0);
       }
@@ -453,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
         const v4h c1 = *reinterpret_cast<const v4h*>(&Vl[d * VP + 16 * s2 + 8 + 4 * lh]);
         const v8h vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         const v8h vl = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-        if (!p.single) {
+        if (!kSingleProduct) {
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s2], acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s2], acc[t], 0, 0, 0);
         }
@@ -702,7 +729,6 @@ static int attn_fwd_impl(const MspiAttnDesc* d, const float* q, const float* k, 
   a.q = q; a.k = k; a.v = v; a.res = res; a.biasT = biasT; a.maskT = maskT; a.tok_idx = tok_idx; a.o = o;
   a.B = d->B; a.Hh = d->Hh; a.Nq = d->Nq; a.Nk = d->Nk; a.nmask = d->nmask > 0 ? d->nmask : 1;
   a.nwin = d->nwin > 0 ? d->nwin : 1;
-  a.single = single_product();
   a.kp = a.vp = nullptr; a.Nkp = 0;
   a.q_sB = d->q_sB; a.q_sH = d->q_sH; a.q_sT = d->q_sT;
   a.k_sB = d->k_sB; a.k_sH = d->k_sH; a.k_sT = d->k_sT;
@@ -717,10 +743,15 @@ static int attn_fwd_impl(const MspiAttnDesc* d, const float* q, const float* k, 
     a.kp = reinterpret_cast<_Float16*>(ws);
     a.vp = a.kp + (size_t)d->B * d->Hh * 2 * a.Nkp * d->D;
     dim3 pgrid((unsigned)(a.Nkp / 32), (unsigned)(d->B * d->Hh));
+    // next tile's planes fetched into registers under the current tile's MFMAs: same-box A/B on the MViTv2-S shapes 2.377 ->
+    // 2.244 ms per forward, better or equal on every shape.  MSPI_ATTN_PF=0 switches it off for an A/B.
+    static const char* pf_env = getenv("MSPI_ATTN_PF");
+    const bool pf = !(pf_env && pf_env[0] == '0');
 #define MSPI_ATTN_PL(DD, DVV)                                                                        \
   case DD * 1000 + DVV:                                                                              \
     hipLaunchKernelGGL((attn_kv_planes_kernel<DD, DVV>), pgrid, dim3(256), 0, s, a);                 \
-    hipLaunchKernelGGL((attn_f16x3_kernel<DD, DVV, true>), grid, dim3(256), 0, s, a);                \
+    if (pf) hipLaunchKernelGGL((attn_f16x3_kernel<DD, DVV, true, true>), grid, dim3(256), 0, s, a);  \
+    else hipLaunchKernelGGL((attn_f16x3_kernel<DD, DVV, true, false>), grid, dim3(256), 0, s, a);    \
     break;
     switch (key) {
       MSPI_ATTN_PL(32, 32) MSPI_ATTN_PL(64, 64) MSPI_ATTN_PL(96, 96) MSPI_ATTN_PL(128, 128) MSPI_ATTN_PL(128, 96) MSPI_ATTN_PL(160, 96)

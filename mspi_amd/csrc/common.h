@@ -30,13 +30,16 @@ inline int check_launch(const char* what) {
     }                             \
   } while (0)
 
-// MSPI_F16_PRODUCTS=1: measurement switch -- every f16x3 kernel issues only the hi*hi MFMA of its three split products, i.e.
-// plain f16 operands with fp32 accumulation (BASELINE configs[4] "fp16 MFMA").  Same data path, a third of the MFMAs.
-// DESIGN.md section 5 records what that costs in accuracy on the golden vectors; the default (3) is the fp32-accurate product.
-inline int single_product() {
-  static const int v = (getenv("MSPI_F16_PRODUCTS") && atoi(getenv("MSPI_F16_PRODUCTS")) == 1) ? 1 : 0;
-  return v;
-}
+// -DMSPI_F16_SINGLE_PRODUCT (make SINGLE=1 -> libmspi_hip_single.so, selected with MSPI_LIB_PATH): measurement build in which
+// every f16x3 kernel issues only the hi*hi MFMA of its three split products, i.e. plain f16 operands with fp32 accumulation
+// (BASELINE configs[4] "fp16 MFMA").  Same data path, a third of the MFMAs.  DESIGN.md section 5 records what that costs in
+// accuracy on the golden vectors.  A COMPILE-time constant on purpose: a run-time flag puts a branch around two of every
+// three MFMAs, and those basic-block boundaries break the MFMA / LDS-read interleaving of the production kernels.
+#ifdef MSPI_F16_SINGLE_PRODUCT
+constexpr bool kSingleProduct = true;
+#else
+constexpr bool kSingleProduct = false;
+#endif
 
 // Range guard of the f16x3 kernels.  An activation with |x| >= 65504 becomes inf in its f16 hi half and the product sums turn
 // into inf / NaN: every GEMM epilogue checks its pre-activation results and, on a non-finite one, stores 1 into the status

@@ -38,7 +38,6 @@ struct ConvArgs {
   int tiles_n, nblocks;
   float out_scale;  // F16X3: 1 / (power-of-two weight pre-scale), applied to the accumulator
   int* status;      // range guard (common.h): set to 1 when an output is not finite; may be NULL
-  int single;       // 1: hi*hi product only (common.h single_product())
   int dbg;          // ablation switches for tools/gemm_probe.py (MSPI_CONV_DBG); 0 in production
   int ksplit;       // split-K: gridDim.y workgroups share an output tile, each owns a contiguous range of K steps ...
   float* ws;        // ... and writes its partial sums to ws[z][M][Cout] (no bias / residual / activation); NULL: no split

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          if (!p.single) {
+          if (!kSingleProduct) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           }
@@ -459,7 +459,6 @@ static int conv_fwd_impl(const MspiConvDesc* d, const float* x, const float* w, 
   a.ldy = d->ldy; a.ldw = d->ldw; a.ldr = d->ldr; a.act = d->act;
   a.M = (int)Ml; a.K = (int)K; a.rows_per_sample = To * Ho * Wo;
   a.out_scale = d->prec == PREC_F16X3 ? 1.0f / d->w_scale : 1.0f;
-  a.single = single_product();
   a.status = g_status_word;
   static const int dbg = getenv("MSPI_CONV_DBG") ? atoi(getenv("MSPI_CONV_DBG")) : 0;
   a.dbg = dbg;
@@ -622,7 +621,6 @@ extern "C" int mspi_gemm_sp_fwd(const MspiConvDesc* d, const void* x_planes, int
   a.ldy = d->ldy; a.ldw = d->ldw; a.ldr = d->ldr; a.act = d->act;
   a.M = (int)Ml; a.K = d->C; a.rows_per_sample = d->T * d->H * d->W;
   a.out_scale = 1.0f / d->w_scale;
-  a.single = single_product();
   a.status = g_status_word;
   a.dbg = 0; a.ws = nullptr; a.ksplit = 1;
   a.xs = (const _Float16*)x_planes; a.ldxs = ldx; a.xplane = xplane;

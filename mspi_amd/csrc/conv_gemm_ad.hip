@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
   auto frag_mfma = [&](const Frag& f) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      if (!p.single) {
+      if (!kSingleProduct) {
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.bh[j], acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.bl[j], acc[j], 0, 0, 0);
       }

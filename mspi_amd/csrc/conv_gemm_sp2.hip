@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, (64 * (TMW + TNW) * 128 * NST <= 80 * 1024) ? 
     for (int i = 0; i < TMW; ++i)
 #pragma unroll
       for (int j = 0; j < TNW; ++j) {
-        if (!p.single) {
+        if (!kSingleProduct) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
         }

@@ -33,7 +33,6 @@ struct MlpArgs {
   int nch;            // hidden / 32
   int ln, act;
   float eps, inv_s1, inv_s2;
-  int single;
   int* status;
 };
 
@@ -167,7 +166,7 @@ __global__ __launch_bounds__(256, (C == 96 && TM == 1) ? (NS == 2 ? 3 : 2) : 1) 
       const v8h wl = *reinterpret_cast<const v8h*>(st + (ks * 2 + 1) * 1024);
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
-        if (!p.single) {
+        if (!kSingleProduct) {
           h[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[t][ks], h[t], 0, 0, 0);
           h[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[t][ks], h[t], 0, 0, 0);
         }
@@ -202,7 +201,7 @@ __global__ __launch_bounds__(256, (C == 96 && TM == 1) ? (NS == 2 ? 3 : 2) : 1) 
         const v8h wl = *reinterpret_cast<const v8h*>(st + W1B + ((s * CT + ct) * 2 + 1) * 1024);
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
-          if (!p.single) {
+          if (!kSingleProduct) {
             o[t][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hh[t][s], o[t][ct], 0, 0, 0);
             o[t][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hl[t][s], o[t][ct], 0, 0, 0);
           }
@@ -276,7 +275,6 @@ extern "C" int mspi_mlp_fwd(const MspiMlpDesc* d, const void* x, const void* gam
   a.M = d->M; a.ldx = d->ldx; a.ldr = d->ldr; a.ldy = d->ldy;
   a.nch = d->hidden / 32; a.ln = d->ln; a.act = d->act; a.eps = d->eps;
   a.inv_s1 = 1.0f / d->w1_scale; a.inv_s2 = 1.0f / d->w2_scale;
-  a.single = single_product();
   a.status = g_status_word;
   static const int variant = getenv("MSPI_MLP_TM") ? atoi(getenv("MSPI_MLP_TM")) : 0;
   int rc;
@@ -309,7 +307,6 @@ struct RowGemmArgs {
   int act;
   float inv_s;
   int rows_per_sample;
-  int single;
   int* status;
 };
 
@@ -385,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void rowgemm_kernel(const RowGemmArgs p) {
     for (int ks = 0; ks < KSB; ++ks) {
       const v8h wh = *reinterpret_cast<const v8h*>(st + (ks * 2 + 0) * 1024);
       const v8h wl = *reinterpret_cast<const v8h*>(st + (ks * 2 + 1) * 1024);
-      if (!p.single) {
+      if (!kSingleProduct) {
         h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[ks], h, 0, 0, 0);
         h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[ks], h, 0, 0, 0);
       }
@@ -469,7 +466,6 @@ extern "C" int mspi_rowgemm_fwd(const MspiRowGemmDesc* d, const void* x, const v
   a.M = d->M; a.ldx = d->ldx; a.ldr = d->ldr; a.ldy = d->ldy; a.ldg = d->ldg;
   a.K = d->K; a.N = d->N; a.nch = (d->N + 31) / 32; a.act = d->act; a.inv_s = 1.0f / d->w_scale;
   a.rows_per_sample = d->rows_per_sample;
-  a.single = single_product();
   a.status = g_status_word;
   const int ksb = rowgemm_ksb(d->K);
   a.cps = rowgemm_cps(d->M, a.nch, ksb);

@@ -32,7 +32,6 @@ struct X3dAbArgs {
   int nch, tiles_w, tiles, nseg, tseg;
   int act;
   float inv_s;
-  int single;
   int* status;
   int dbg;      // ablation switches for tools/x3d_ab_bench.py (MSPI_X3D_DBG): 1 skip the GEMM phase, 2 skip the depthwise phase, 4 no x loads; 0 in production
 };
@@ -136,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void x3d_ab_kernel(const X3dAbArgs p) {
             const unsigned char* wp = x3d_smem + ((s * 2 + at) * 2) * 1024 + lane * 16;
             const v8h_ wh = *reinterpret_cast<const v8h_*>(wp);
             const v8h_ wl = *reinterpret_cast<const v8h_*>(wp + 1024);
-            if (!p.single) {
+            if (!kSingleProduct) {
               acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[s], acc, 0, 0, 0);
               acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[s], acc, 0, 0, 0);
             }
@@ -287,7 +286,6 @@ extern "C" int mspi_x3d_ab_fwd(const MspiX3dAbDesc* d, const void* x, const void
   static const int dbg = getenv("MSPI_X3D_DBG") ? atoi(getenv("MSPI_X3D_DBG")) : 0;
   static const int tseg_env = getenv("MSPI_X3D_TSEG") ? atoi(getenv("MSPI_X3D_TSEG")) : 0;
   a.dbg = dbg;
-  a.single = single_product();
   a.status = g_status_word;
   x3d_geometry(d, a);
   if (tseg_env > 0 && !pool) { a.tseg = tseg_env; a.nseg = (d->T + a.tseg - 1) / a.tseg; }

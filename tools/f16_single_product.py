@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Map-level error of every model-level golden (the reference's own CPU fp32 outputs) under the current GEMM arithmetic.
-Run once as is (f16x3: three split products) and once with MSPI_F16_PRODUCTS=1 (plain f16 operands, fp32 accumulate):
+Run once as is (f16x3: three split products) and once with MSPI_LIB_PATH=mspi_amd/csrc/libmspi_hip_single.so (built by
+`make -C mspi_amd/csrc SINGLE=1`: plain f16 operands, fp32 accumulate):
 the answer to BASELINE configs[4]'s "fp16 MFMA".  Prints one JSON object."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +15,7 @@ GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 CASES = [("av_x3dl_224", "x3dl"), ("av_slowfast_224", "slowfast4x16"), ("av_mvit_224_wa300", "mvitv2s"), ("av_mvit_224x384", "mvitv2s"),
          ("av_swin_t_224", "videoswins"), ("av_swin_s_224", "videoswins"), ("av_s3d_224", "s3d"), ("av_uniformer_224", "uniformerb"),
          ("av_morphmlp_224", "morphmlps"), ("av_x3dl_64", "x3dl"), ("av_slowfast_64", "slowfast4x16")]
-out = {"MSPI_F16_PRODUCTS": os.environ.get("MSPI_F16_PRODUCTS", "3"), "cases": {}}
+out = {"library": os.path.basename(os.environ.get("MSPI_LIB_PATH", "libmspi_hip.so")), "cases": {}}
 so, sys.stdout = sys.stdout, open(os.devnull, "w")
 for case, name in CASES:
     g = np.load(os.path.join(GOLD, case + ".npz"))
