@@ -271,11 +271,14 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
   // f16 loses precision below 2^-14 (subnormals; the matrix pipe may flush them): q*scale ~ 0.1 and p <= 1 would keep
   // only their hi halves.  Scaled, every operand of ordinary magnitude has a NORMAL lo half.
   constexpr float QSC = 64.f, KSC = ATT_KSC, PSC = 1024.f, VSC = ATT_VSC;
-  __shared__ __attribute__((aligned(16))) _Float16 smem[2 * 32 * KP + 2 * DV * VP];
-  _Float16* Kh = smem;
-  _Float16* Kl = smem + 32 * KP;
-  _Float16* Vh = smem + 2 * 32 * KP;
-  _Float16* Vl = Vh + DV * VP;
+  // With prefetched planes (PL && PF) the K / V tiles are DOUBLE-buffered in LDS: tile t+1 is written (from the registers the
+  // prefetch filled) behind tile t's MFMAs, so a key tile costs one barrier, not two, and no wave waits for staging.
+  constexpr int TILE = 2 * 32 * KP + 2 * DV * VP;
+  __shared__ __attribute__((aligned(16))) _Float16 smem[(PL && PF ? 2 : 1) * TILE];
+  _Float16 *Kh = smem, *Kl = smem + 32 * KP, *Vh = smem + 2 * 32 * KP, *Vl = smem + 2 * 32 * KP + DV * VP;
+  auto set_buf = [&](int bsel) {
+    Kh = smem + bsel * TILE; Kl = Kh + 32 * KP; Vh = Kh + 2 * 32 * KP; Vl = Vh + DV * VP;
+  };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -340,36 +343,44 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
       pf_vl[i] = *reinterpret_cast<const uint4*>(gVl + (long)d * p.Nkp + 8 * c);
     }
   };
-  if (PF) prefetch(0);
-
-  for (int k0 = 0; k0 < p.Nk; k0 += 32) {
-    __syncthreads();  // previous tile fully consumed
-    if (PL && !PF) prefetch(k0);
-    if (PL) {
-      // planes made by attn_kv_planes_kernel: staging is a copy -- 16 B per K chunk, 8 + 8 B per V^T chunk (its LDS rows are
-      // 72 B apart), no conversion work.  The chunks of this tile were fetched into registers while the previous tile was
-      // being computed (pf_*), so the only exposed global latency is the first tile's.
+  // planes made by attn_kv_planes_kernel: staging is a copy from the prefetch registers -- 16 B per K chunk, 8 + 8 B per V^T
+  // chunk (its LDS rows are 72 B apart), no conversion work
+  auto stage_write = [&](_Float16* base) {
+    _Float16 *bKh = base, *bKl = base + 32 * KP, *bVh = base + 2 * 32 * KP, *bVl = base + 2 * 32 * KP + DV * VP;
 #pragma unroll
-      for (int i = 0; i < PFK; ++i) {
-        const int idx = tid + 256 * i;
-        if (idx < 32 * (D / 8)) {
-          const int row = idx / (D / 8), c = idx - row * (D / 8);
-          *reinterpret_cast<uint4*>(&Kh[row * KP + 8 * c]) = pf_kh[i];
-          *reinterpret_cast<uint4*>(&Kl[row * KP + 8 * c]) = pf_kl[i];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < PFV; ++i) {
-        const int idx = tid + 256 * i;
-        if (idx < DV * 4) {
-          const int d = idx >> 2, c = idx & 3;
-          *reinterpret_cast<uint2*>(&Vh[d * VP + 8 * c]) = make_uint2(pf_vh[i].x, pf_vh[i].y);
-          *reinterpret_cast<uint2*>(&Vh[d * VP + 8 * c + 4]) = make_uint2(pf_vh[i].z, pf_vh[i].w);
-          *reinterpret_cast<uint2*>(&Vl[d * VP + 8 * c]) = make_uint2(pf_vl[i].x, pf_vl[i].y);
-          *reinterpret_cast<uint2*>(&Vl[d * VP + 8 * c + 4]) = make_uint2(pf_vl[i].z, pf_vl[i].w);
-        }
+    for (int i = 0; i < PFK; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < 32 * (D / 8)) {
+        const int row = idx / (D / 8), c = idx - row * (D / 8);
+        *reinterpret_cast<uint4*>(&bKh[row * KP + 8 * c]) = pf_kh[i];
+        *reinterpret_cast<uint4*>(&bKl[row * KP + 8 * c]) = pf_kl[i];
       }
     }
+#pragma unroll
+    for (int i = 0; i < PFV; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < DV * 4) {
+        const int d = idx >> 2, c = idx & 3;
+        *reinterpret_cast<uint2*>(&bVh[d * VP + 8 * c]) = make_uint2(pf_vh[i].x, pf_vh[i].y);
+        *reinterpret_cast<uint2*>(&bVh[d * VP + 8 * c + 4]) = make_uint2(pf_vh[i].z, pf_vh[i].w);
+        *reinterpret_cast<uint2*>(&bVl[d * VP + 8 * c]) = make_uint2(pf_vl[i].x, pf_vl[i].y);
+        *reinterpret_cast<uint2*>(&bVl[d * VP + 8 * c + 4]) = make_uint2(pf_vl[i].z, pf_vl[i].w);
+      }
+    }
+  };
+  if (PL && PF) {
+    prefetch(0);
+    stage_write(smem);
+    if (32 < p.Nk) prefetch(32);
+    __syncthreads();
+  }
+
+  int tsel = 0;
+  for (int k0 = 0; k0 < p.Nk; k0 += 32, tsel ^= 1) {
+    if (PL && PF) set_buf(tsel);
+    if (!(PL && PF)) __syncthreads();  // previous tile fully consumed
+    if (PL && !PF) prefetch(k0);
+    if (PL && !PF) stage_write(smem);
     // K: thread -> (key row, 4 d): two 8-B plane writes
     for (int idx = tid; !PL && idx < 32 * (D / 4); idx += 256) {
       const int row = idx / (D / 4), c4 = idx - row * (D / 4);
@@ -405,8 +416,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
         *reinterpret_cast<v2h*>(&Vl[(c4 * 4 + j) * VP + 2 * kp]) = pl;
       }
     }
-    __syncthreads();
-    if (PL && PF && k0 + 32 < p.Nk) prefetch(k0 + 32);      // in flight under this tile's MFMAs and softmax
+    if (!(PL && PF)) __syncthreads();
 
     // S^T = K . Q^T
     v16f s;
@@ -486,6 +496,13 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
         }
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s2], acc[t], 0, 0, 0);
       }
+    if (PL && PF) {
+      if (k0 + 32 < p.Nk) {
+        stage_write(smem + (tsel ^ 1) * TILE);                 // tile t+1 (fetched during this tile) into the other buffer
+        if (k0 + 64 < p.Nk) prefetch(k0 + 64);
+      }
+      __syncthreads();                                         // tile t consumed by every wave, tile t+1 visible
+    }
   }
 
   if (qok) {
