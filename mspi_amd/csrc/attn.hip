@@ -771,9 +771,9 @@ static int attn_fwd_impl(const MspiAttnDesc* d, const float* q, const float* k, 
     else hipLaunchKernelGGL((attn_f16x3_kernel<DD, DVV, true, false>), grid, dim3(256), 0, s, a);    \
     break;
     switch (key) {
-      MSPI_ATTN_PL(32, 32) MSPI_ATTN_PL(64, 64) MSPI_ATTN_PL(96, 96) MSPI_ATTN_PL(128, 128) MSPI_ATTN_PL(128, 96) MSPI_ATTN_PL(160, 96)
+      MSPI_ATTN_PL(32, 32) MSPI_ATTN_PL(64, 64) MSPI_ATTN_PL(96, 96) MSPI_ATTN_PL(128, 128) MSPI_ATTN_PL(128, 96) MSPI_ATTN_PL(144, 96) MSPI_ATTN_PL(160, 96)
       default:
-        set_error("mspi_attn_fwd_ws: (D=%d, Dv=%d) not in {(32,32),(64,64),(96,96),(128,128),(128,96),(160,96)}", d->D, d->Dv);
+        set_error("mspi_attn_fwd_ws: (D=%d, Dv=%d) not in {(32,32),(64,64),(96,96),(128,128),(128,96),(144,96),(160,96)}", d->D, d->Dv);
         return MSPI_EINVAL;
     }
 #undef MSPI_ATTN_PL
@@ -786,9 +786,10 @@ static int attn_fwd_impl(const MspiAttnDesc* d, const float* q, const float* k, 
       case 96096: hipLaunchKernelGGL((attn_f16x3_kernel<96, 96>), grid, dim3(256), 0, s, a); break;
       case 128128: hipLaunchKernelGGL((attn_f16x3_kernel<128, 128>), grid, dim3(256), 0, s, a); break;
       case 128096: hipLaunchKernelGGL((attn_f16x3_kernel<128, 96>), grid, dim3(256), 0, s, a); break;
+      case 144096: hipLaunchKernelGGL((attn_f16x3_kernel<144, 96>), grid, dim3(256), 0, s, a); break;
       case 160096: hipLaunchKernelGGL((attn_f16x3_kernel<160, 96>), grid, dim3(256), 0, s, a); break;
       default:
-        set_error("mspi_attn_fwd: (D=%d, Dv=%d) not in {(32,32),(64,64),(96,96),(128,128),(128,96),(160,96)}", d->D, d->Dv);
+        set_error("mspi_attn_fwd: (D=%d, Dv=%d) not in {(32,32),(64,64),(96,96),(128,128),(128,96),(144,96),(160,96)}", d->D, d->Dv);
         return MSPI_EINVAL;
     }
     return check_launch("mspi_attn_fwd");
@@ -800,9 +801,10 @@ static int attn_fwd_impl(const MspiAttnDesc* d, const float* q, const float* k, 
     case 96096: hipLaunchKernelGGL((attn_kernel<96, 96>), grid, dim3(256), 0, s, a); break;
     case 128128: hipLaunchKernelGGL((attn_kernel<128, 128>), grid, dim3(256), 0, s, a); break;
     case 128096: hipLaunchKernelGGL((attn_kernel<128, 96>), grid, dim3(256), 0, s, a); break;
+    case 144096: hipLaunchKernelGGL((attn_kernel<144, 96>), grid, dim3(256), 0, s, a); break;
     case 160096: hipLaunchKernelGGL((attn_kernel<160, 96>), grid, dim3(256), 0, s, a); break;
     default:
-      set_error("mspi_attn_fwd: (D=%d, Dv=%d) not in {(32,32),(64,64),(96,96),(128,128),(128,96),(160,96)}", d->D, d->Dv);
+      set_error("mspi_attn_fwd: (D=%d, Dv=%d) not in {(32,32),(64,64),(96,96),(128,128),(128,96),(144,96),(160,96)}", d->D, d->Dv);
       return MSPI_EINVAL;
   }
   return check_launch("mspi_attn_fwd");

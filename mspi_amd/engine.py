@@ -155,7 +155,7 @@ def _need_gpu(t):
 #    contract as cudnn.benchmark upstream, inference.py:19): max|x| of the layer's input outside [2^-5, 2^15] moves THAT layer
 #    to the fp32 MFMA path (exact fp32 fmaf chain, 5.3x the MFMA time) for good.  MSPI_RANGE_CHECK=0 disables it.
 _STATUS = {"word": None}
-RANGE_CHECK = {"on": _os.environ.get("MSPI_RANGE_CHECK", "1") != "0", "lo": 2.0 ** -5, "hi": 2.0 ** 15, "seen": set(), "moved": []}
+RANGE_CHECK = {"on": _os.environ.get("MSPI_RANGE_CHECK", "1") != "0", "lo": 2.0 ** -5, "hi": 2.0 ** 15, "moved": []}
 
 
 def _register_status_word():
@@ -188,9 +188,9 @@ def check_range(sync=True):
 
 def _range_check(pk, amax_fn, what):
     """First sight of a pack while tuning: move it to the fp32 path if its input's magnitude is outside the f16x3 window."""
-    if id(pk) in RANGE_CHECK["seen"]:
+    if pk.checked:
         return
-    RANGE_CHECK["seen"].add(id(pk))
+    pk.checked = True
     amax = float(amax_fn())
     if not (amax == amax) or amax >= RANGE_CHECK["hi"] or 0.0 < amax < RANGE_CHECK["lo"]:
         pk.w, pk.ldw, pk.prec, pk.thin, pk.w_scale = pk.w32, pk.ldw32, PREC_F32, None, 1.0
@@ -311,7 +311,7 @@ def fold_bn(weight, bias, bn):
 
 class PackedConv:
     __slots__ = ("w", "bias", "k", "stride", "pad", "cin", "cin_s", "cout", "cout_s", "ldw", "act", "prec", "w_scale", "thin",
-                 "w32", "ldw32")
+                 "w32", "ldw32", "checked")
 
 
 def pack_conv(weight, bias=None, bn=None, stride=(1, 1, 1), pad=(0, 0, 0), act=ACT_NONE, cin_stored=None,
@@ -340,6 +340,7 @@ def pack_conv(weight, bias=None, bn=None, stride=(1, 1, 1), pad=(0, 0, 0), act=A
     wf[:, :K] = wp.reshape(cout_s, K)
     p = PackedConv()
     p.thin = None
+    p.checked = False
     dev = w.device if device is None else device
     p.prec, p.w_scale = prec, 1.0
     if prec == PREC_F16X3:
@@ -936,7 +937,7 @@ def mvit_attention(q, k, v, B, heads, hd, scale, q_thw, k_thw, Rh, Rw, Rt, out=N
     lib = _lib.load()
     Nq, Nk = q_thw[0] * q_thw[1] * q_thw[2], k_thw[0] * k_thw[1] * k_thw[2]
     J = k_thw[0] + k_thw[1] + k_thw[2]
-    DA = 128 if hd + J <= 128 else 160
+    DA = 128 if hd + J <= 128 else (144 if hd + J <= 144 else 160)      # k16 steps of S: 8 / 9 / 10
     if hd != 96 or hd + J > DA:
         raise MspiError("mvit_attention: head_dim %d with %d relative-position columns is not instantiated" % (hd, J))
     dev = q.buf.device
