@@ -41,6 +41,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
 #ifndef MSPI_DMA_NST_SP
 #define MSPI_DMA_NST_SP 2
 #endif
+#ifndef MSPI_SP_READS_FIRST
+#define MSPI_SP_READS_FIRST 0   // A/B builds: 1 = all fragment reads of a stage before its MFMAs, 2 = + MFMAs pinned before the DMA wait.
+#endif                          // Same-box result on six layers (tile 7): 146/128/140/144/162/199 us vs 150/130/144/138/167/204 vs
+                                // 149/126/140/146/160/202 -- the loop's instruction order is not what bounds this kernel
   // measured: a 3-deep ring (BN <= 64) loses a resident workgroup to LDS and is 15-25 % slower (fp32-A form, round 1);
   // -DMSPI_DMA_NST_SP=3 builds the pre-split 128 x 64 form with a 3-deep ring for an A/B (tools/sp_probe.py, MSPI_LIB_PATH)
   constexpr int NST = (APRE && BN == 64 && NW == 4) ? MSPI_DMA_NST_SP : 2;
@@ -237,13 +241,22 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
       frag_read(f1, cur, 1, it * BK);
       frag_split(f1);
       frag_mfma(f0);
+      if (APRE && MSPI_SP_READS_FIRST) {
+        // pre-split operands: there is no VALU to hide, only LDS latency.  Interleaved 1:1 the compiler put an
+        // `s_waitcnt lgkmcnt(0)` in front of every MFMA (each fragment read's latency exposed behind ONE 32-cycle MFMA); with
+        // all 4 + 8 TN/2... reads of the stage issued first, the MFMAs wait with counted lgkmcnt and only the first pays
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 + 4 * TN, 0);   // every DS read of both sub-steps
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * TN, 0);       // then the MFMAs
+      } else {
 #pragma unroll
-      for (int g = 0; g < 3 * TN; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-        if (!APRE) __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // 5 VALU (the hi/lo split)
+        for (int g = 0; g < 3 * TN; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+          if (!APRE) __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // 5 VALU (the hi/lo split)
+        }
       }
       frag_mfma(f1);
+      if (APRE && MSPI_SP_READS_FIRST == 2) __builtin_amdgcn_sched_barrier(0);   // MFMAs are issued BEFORE the wait for the next stage's DMA
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my DMAs have landed ...
       __syncthreads();                                         // ... and so have everybody else's; stage `cur` is free
     }

@@ -7,6 +7,7 @@ from mspi_amd import engine as E, _lib
 
 dev = torch.device("cuda")
 lib = _lib.load()
+import os as _os
 SHAPES = [(25088, 384, 1536), (25088, 1536, 384), (6272, 768, 3072), (6272, 3072, 768), (100352, 768, 192), (100352, 192, 768),
           (6992, 512, 2048), (6992, 2048, 512), (12544, 320, 1280), (12544, 1280, 320)]
 
@@ -24,6 +25,8 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
+if _os.environ.get("SP_PROBE_SHAPES"):
+    SHAPES = SHAPES[: int(_os.environ["SP_PROBE_SHAPES"])]
 g = torch.Generator().manual_seed(0)
 for M, K, N in SHAPES:
     x = torch.randn(M, K, generator=g).to(dev)
