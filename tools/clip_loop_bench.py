@@ -6,6 +6,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 LAYOUTS = int(os.environ.get("CLB_LAYOUTS", "3"))
+DEPTH = int(os.environ.get("CLB_DEPTH", "2"))
 ONLY_GRAPH = os.environ.get("CLB_ONLY_GRAPH") == "1"      # as mspi_amd.inference's entry does (runtime.configure_hw_queues)
 import torch
 from mspi_amd import engine as E, testing as T
@@ -40,7 +41,7 @@ KEEP = {}
 
 
 def run(cached, graph):
-    feats, nxt, t0, n, out, pipe, prev = {}, 0, None, 0, None, None, None
+    feats, nxt, t0, n, out, pipe, prev, pend = {}, 0, None, 0, None, None, None, []
     for step, first in enumerate(range(0, n_frames - 16 - B + 1, B)):
         if step == 3:                      # three warm-up batches (tuning, allocator, capture)
             torch.cuda.synchronize(); t0 = time.perf_counter(); n = 0
@@ -65,7 +66,7 @@ def run(cached, graph):
              (lambda c, a: E.postprocess_u8(m(c, a)[0], OUT))
         if graph:
             if pipe is None:
-                pipe = GraphPipeline(fn, inputs, depth=2, layouts=LAYOUTS)
+                pipe = GraphPipeline(fn, inputs, depth=DEPTH, layouts=LAYOUTS)
                 idle = pipe.idle_streams(2)
                 pipe._copy_stream = idle[0]
                 if not os.environ.get("CLB_KEEP_STREAM"):
@@ -83,6 +84,8 @@ def run(cached, graph):
             else:
                 t = pipe.submit(*inputs)
             tb = time.perf_counter()
+            pend.append(t)
+            prev = pend.pop(0) if len(pend) >= DEPTH else None
             if prev is not None:
                 pipe.fetch(prev)
                 tc = time.perf_counter()
@@ -90,12 +93,12 @@ def run(cached, graph):
                 if os.environ.get("CLB_DEBUG"):
                     print("    step %2d: build %.1f ms, submit %.1f, wait for previous batch %.1f, D2H + clone %.1f" % (
                         step, 1e3 * (ta - t_it), 1e3 * (tb - ta), 1e3 * (tc - tb), 1e3 * (time.perf_counter() - tc)), flush=True)
-            prev = t
         else:
             out = fn(*inputs).cpu()
         n += B
     if graph:
-        out = pipe.fetch_host(prev).clone()
+        for t in pend:
+            out = pipe.fetch_host(t).clone()
     torch.cuda.synchronize()
     return n / (time.perf_counter() - t0), out
 
