@@ -207,6 +207,9 @@ __device__ __forceinline__ void split4(const float4 v, v4h& hi, v4h& lo) {
   }
 }
 
+#ifndef MSPI_ATT_PV_DROP
+#define MSPI_ATT_PV_DROP 0
+#endif
 constexpr float ATT_KSC = 16.f, ATT_VSC = 16.f;
 
 // K and V of every (sequence, head) split ONCE into the f16 hi/lo planes the attention kernel stages: every query tile of
@@ -490,10 +493,10 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
         const v4h c1 = *reinterpret_cast<const v4h*>(&Vl[d * VP + 16 * s2 + 8 + 4 * lh]);
         const v8h vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         const v8h vl = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-        if (!kSingleProduct) {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s2], acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s2], acc[t], 0, 0, 0);
-        }
+        // -DMSPI_ATT_PV_DROP=1 / 2 / 3: measurement builds without the V_hi.P_lo / V_lo.P_hi / both cross products of
+        // O^T += V^T.P^T (which of them the 1e-3 bar on the map tolerates)
+        if (!kSingleProduct && !(MSPI_ATT_PV_DROP & 2)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s2], acc[t], 0, 0, 0);
+        if (!kSingleProduct && !(MSPI_ATT_PV_DROP & 1)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s2], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s2], acc[t], 0, 0, 0);
       }
     if (PL && PF) {
