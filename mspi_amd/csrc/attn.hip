@@ -436,7 +436,8 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
       s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], s, 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] *= p.scale * (1.f / (QSC * KSC));
+    // logits in LOG2 units: log2(e) rides on the scale, the exponentials below are bare v_exp_f32
+    for (int r = 0; r < 16; ++r) s[r] *= p.scale * (1.4426950408889634f / (QSC * KSC));
 
     // online softmax over the 32 keys of this tile (16 in my registers, 16 in lane^32's)
     float mt = -INFINITY;
@@ -451,22 +452,25 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
         add[r] = (bt ? bt[o] : 0.f) + (mk ? mk[o] : 0.f);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] += add[r];
+      for (int r = 0; r < 16; ++r) s[r] = fmaf(add[r], 1.4426950408889634f, s[r]);
+    }
+    if (k0 + 32 > p.Nk) {      // only the last tile has keys past the end (wave-uniform branch)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (key >= p.Nk) s[r] = -INFINITY;
+      }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (key >= p.Nk) s[r] = -INFINITY;
-      mt = fmaxf(mt, s[r]);
-    }
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m_run, mt);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float ps = 0.f;
     v8h ph[2], pl[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = __expf(s[r] - m_new);
+      const float e = __builtin_amdgcn_exp2f(s[r] - m_new);
       ps += e;
       _Float16 hi, lo;
       split_f16(e * PSC, hi, lo);
@@ -476,10 +480,12 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
     ps += __shfl_xor(ps, 32, 64);
     l_run = l_run * alpha + ps;
     m_run = m_new;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {      // no row of this wave raised its maximum: nothing to rescale
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
+        for (int r = 0; r < 16; ++r) acc[t][r] *= alpha;
+    }
 
     // O^T += V^T . P^T
 #pragma unroll
