@@ -133,9 +133,8 @@ class GraphPipeline:
             if s.busy:
                 s.done.synchronize()                               # the batch this slot ran `depth` submits ago
             # The caller's tensors are kept alive HERE until this slot's replay has been waited for -- not handed to the
-            # allocator with record_stream(): a block with a pending cross-stream use cannot be reused, so every submit grew
-            # the pool by a fresh hipMalloc, and hipMalloc synchronises the device (measured: a 50-75 ms stall every third
-            # batch of the clip loop).
+            # allocator with record_stream(): a block with a pending cross-stream use cannot be reused until that stream's
+            # event has passed, so per-batch inputs would keep growing the pool through hipMalloc, which synchronises the device.
             s.keep = inputs
             produced = torch.cuda.Event()
             produced.record()                                      # on the producer's (current) stream
