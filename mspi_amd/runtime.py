@@ -105,7 +105,7 @@ class GraphPipeline:
         s.done.record()
 
     @staticmethod
-    def _rate(slots, n=8):
+    def _rate(slots, n=12):
         def go(i):
             s = slots[i % len(slots)]
             with torch.cuda.stream(s.stream):
