@@ -361,7 +361,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
       for (int r = 0; r < 16; ++r) {
         const int row = rb0 + (r & 3) + 8 * (r >> 2);
         const float v = (PREC == PREC_F32 ? acc[i][j][r] : acc[i][j][r] * p.out_scale) + bv + rv[r];
-        bad |= nonfinite(v);
+        bad |= row < p.M && nonfinite(v);          // padding rows of the last tile carry no result: never flagged
         if (row < p.M) p.y[(long)row * p.ldy + col] = act_apply(v, p.act);
       }
     }
@@ -389,7 +389,6 @@ namespace mspi {
 int launch_conv_ad(ConvArgs& a, long Ml, int force_bn, int* cfg, hipStream_t s);
 int launch_conv_ad8(ConvArgs& a, long Ml, int bn, int* cfg, hipStream_t s);
 int launch_conv_sp(ConvArgs& a, long Ml, int bn, int rows, int* cfg, hipStream_t s);
-int launch_conv_sp2(ConvArgs& a, long Ml, int variant, int* cfg, hipStream_t s);   // conv_gemm_sp2.hip
 }
 
 static thread_local int g_last_cfg = 0;
@@ -638,8 +637,7 @@ extern "C" int mspi_gemm_sp_fwd(const MspiConvDesc* d, const void* x_planes, int
     default: bn = d->Cout <= 64 ? 64 : (d->Cout % 192 == 0 ? 192 : 128); break;
   }
   int cfg = 0;
-  const int rc = (d->tile >= 15 && d->tile <= 18) ? launch_conv_sp2(a, Ml, d->tile - 15, &cfg, (hipStream_t)stream)
-                                                  : launch_conv_sp(a, Ml, bn, rows, &cfg, (hipStream_t)stream);
+  const int rc = launch_conv_sp(a, Ml, bn, rows, &cfg, (hipStream_t)stream);
   MSPI_REQUIRE(rc == 0, "mspi_gemm_sp_fwd: tile %d could not be launched", d->tile);
   g_last_cfg = cfg;
   return check_launch("mspi_gemm_sp_fwd");

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
         for (int e = 0; e < 2; ++e) {
           const int r = 2 * q + e;
           const float pre = acc[j][r] * p.out_scale + bv + rv[r];
-          bad |= nonfinite(pre);
+          bad |= rb0 + (r & 3) + 8 * (r >> 2) < p.M && nonfinite(pre);      // padding rows are never flagged
           const float v = act_apply(pre, p.act);
           _Float16 h, l;
           split_f16(v, h, l);
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
     for (int r = 0; r < 16; ++r) {
       const int row = rb0 + (r & 3) + 8 * (r >> 2);
       const float pre = acc[j][r] * p.out_scale + bv + rv[r];
-      bad |= nonfinite(pre);
+      bad |= row < p.M && nonfinite(pre);
       if (row < p.M) p.y[(long)row * p.ldy + col] = act_apply(pre, p.act);
     }
   }
