@@ -275,6 +275,9 @@ size_t mspi_x3d_stage_packed_bytes(const MspiX3dStageDesc* d, size_t* float_para
 size_t mspi_x3d_stage_ws_bytes(const MspiX3dStageDesc* d);
 int mspi_x3d_stage_fwd(const MspiX3dStageDesc* d, const void* x, void* y, const void* wq, const void* wf, void* ws,
                        mspi_stream_t stream);
+/* Diagnostic: while buf != NULL (device memory, 16 * nblocks * 256 uint64) the kernel records 100 MHz time stamps per workgroup,
+ * block and phase (tools/x3d_stage_debug.py); NULL (the default) switches them off. */
+int mspi_x3d_stage_debug_stamps(void* buf);
 
 /* ------------------------------------------------------------------------------------
  * Max pooling, channels-last, -inf padding.

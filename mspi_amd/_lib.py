@@ -158,6 +158,7 @@ _SIGNATURES = {
     "mspi_x3d_stage_packed_bytes": (C.c_size_t, [C.POINTER(X3dStageDesc), C.POINTER(C.c_size_t)]),
     "mspi_x3d_stage_ws_bytes": (C.c_size_t, [C.POINTER(X3dStageDesc)]),
     "mspi_x3d_stage_fwd": (C.c_int, [C.POINTER(X3dStageDesc), _P, _P, _P, _P, _P, _P]),
+    "mspi_x3d_stage_debug_stamps": (C.c_int, [_P]),
     "mspi_mlp_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "mspi_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mspi_postprocess_workspace": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

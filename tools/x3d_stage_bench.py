@@ -76,3 +76,36 @@ for mode in ("0", "1"):
             "on" if mode == "1" else "off", depth, ms, B * 1.33 / ms / 8.0), flush=True)
 torch.cuda.synchronize()
 E.check_range()
+
+# ---- where a block's time goes: 100 MHz stamps per workgroup, block and phase (median over workgroups and blocks)
+import ctypes as C
+from mspi_amd import _lib
+lib = _lib.load()
+E.X3D_STAGE["mode"] = "1"
+y = x3d.s1.run([clips]); y = x3d.s2.run(y); y = x3d.s3.run(y)
+for name, st in (("s4", x3d.s4), ("s5", x3d.s5)):
+    xin = stage_input(st, y[0])
+    spk = st.pk[0]
+    nb = spk.nblocks
+    stamps = torch.zeros(256 * nb * 16, dtype=torch.int64, device=dev)
+    lib.mspi_x3d_stage_debug_stamps(stamps.data_ptr())
+    for _ in range(3):
+        E.x3d_stage(xin, spk)
+    torch.cuda.synchronize()
+    lib.mspi_x3d_stage_debug_stamps(None)
+    s_ = stamps.view(256, nb, 16).double() * 0.01       # us
+    se = torch.tensor([(spk.se_mask >> k) & 1 for k in range(nb)], dtype=torch.bool, device=dev)
+    seg = {"A: a-GEMM + publish": s_[:, :, 1] - s_[:, :, 0], "wait for neighbours' t": s_[:, :, 2] - s_[:, :, 1],
+           "B: depthwise": s_[:, :, 3] - s_[:, :, 2], "SE: arrive + wait": (s_[:, :, 6] - s_[:, :, 3])[:, se],
+           "SE: gate + planes": (s_[:, :, 4] - s_[:, :, 6])[:, se],
+           "C: c-GEMM (SE blocks)": (s_[:, :, 5] - s_[:, :, 4])[:, se], "C: c-GEMM (plain blocks)": (s_[:, :, 5] - s_[:, :, 3])[:, ~se],
+           "  dw chunk 3: wait loads + LDS write": s_[:, :, 9] - s_[:, :, 8], "  dw chunk 3: barrier": s_[:, :, 10] - s_[:, :, 9],
+           "  dw chunk 3: issue next loads": s_[:, :, 11] - s_[:, :, 10], "  dw chunk 3: compute + stores": s_[:, :, 12] - s_[:, :, 11],
+           "  dw chunk 3: barrier 2": s_[:, :, 13] - s_[:, :, 12],
+           "block (SE)": (s_[:, 1:, 0] - s_[:, :-1, 0])[:, se[:-1]], "block (plain)": (s_[:, 1:, 0] - s_[:, :-1, 0])[:, ~se[:-1]]}
+    print("%s: per-phase time inside the stage kernel, us (median / mean / max over workgroups x blocks)" % name)
+    for kname, v in seg.items():
+        print("   %-38s %6.2f %6.2f %6.2f" % (kname, v.median().item(), v.mean().item(), v.max().item()))
+    E.X3D_STAGE["mode"] = "0"
+    y = st.run(y)
+    E.X3D_STAGE["mode"] = "1"

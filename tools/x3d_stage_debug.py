@@ -50,7 +50,7 @@ for stage, bidx in ((x3d.s4, 1), (x3d.s4, 2), (x3d.s5, 1), (x3d.s5, 2)):
     n = Tt and min(H, 32 // Tt)
     TH = (H + n - 1) // n
     Pn = Tt * ((H + TH - 1) // TH)
-    off = al((N * Pn + N + 1) * 4)
+    off = al((N * Pn + N + 1 + 8 * Pn + 8) * 4)
     tb = ws[off: off + 2 * M * Ds * 4].view(torch.float32).view(2, M, Ds); off += al(2 * M * Ds * 4)
     ub = ws[off: off + M * Ds * 4].view(torch.float32).view(M, Ds); off += al(M * Ds * 4)
     KU = (Ds + 15) // 16 * 16
