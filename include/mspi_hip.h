@@ -247,39 +247,6 @@ int mspi_x3d_ab_fwd(const MspiX3dAbDesc* d, const void* x, const void* wa_packed
                     const void* bias_b, void* u, void* pool /*or NULL*/, mspi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
- * X3D res-stage as ONE persistent launch (csrc/x3d_stage.hip): the stride-1 blocks 1..n-1 of a stage,
- *   per block  x <- relu( x + c_bn(c( swish( [se(.)] b_bn(b( relu(a_bn(a(x))) )) ) )) )
- * Replaces ResStage.forward's loop over ResBlock / X3DTransform (SlowFast/resnet_helper.py:296-351, SE :27-73, Swish :76-103,
- * ResBlock :593-616, ResStage :790-825) for blocks whose dim_in == dim_out and stride == 1.  One sample per group of <= 32
- * workgroups; between the blocks only the 1-position halo of the expanded tensor and the squeeze-excite pool sums cross
- * workgroups (write-through stores + epoch words, bounded polls: a timeout stores 2 into the status word and the output is
- * invalid -- it happens only when the grid is not co-resident, e.g. more than two such launches in flight on one GPU).
- * x, y: dense [N,T,H,W,C] fp32 rows (x != y).  C % 32 == 0, D = dim_inner (stored as rup4), F = SE hidden width,
- * se_mask bit k: block k (0-based among the blocks given) has squeeze-excite.
- * wq: per block mspi_x3d_stage_packed_bytes(d, &nf) bytes of f16 MFMA fragments (weights times their power-of-two scale, BN
- *   folded): a as [ks < C/16][chunk < ceil(Ds/32)][hi,lo][lane][8] = Wa[chunk*32 + lane%32][16 ks + 8 (lane/32) + e], then c
- *   as [ks < ceil(Ds/16)][chunk < C/32][hi,lo][lane][8] likewise (zero padded).
- * wf: per block nf floats (stride rounded up to a multiple of 4): bias_a[32 ceil(Ds/32)] bias_c[C] bias_b[Ds] wb[27][Ds]
- *   se_w1[F][Ds] se_b1[F] se_w2[Ds][F] se_b2[Ds] 1/a_scale 1/c_scale.
- * ws: mspi_x3d_stage_ws_bytes(d) bytes of device scratch (the caller's; contents need not be preserved between calls).
- * ------------------------------------------------------------------------------------ */
-typedef struct MspiX3dStageDesc {
-  int32_t N, T, H, W;
-  int32_t C, D, F;
-  int32_t nblocks;
-  uint32_t se_mask;
-} MspiX3dStageDesc;
-
-int mspi_x3d_stage_supported(const MspiX3dStageDesc* d);
-size_t mspi_x3d_stage_packed_bytes(const MspiX3dStageDesc* d, size_t* float_params_per_block);
-size_t mspi_x3d_stage_ws_bytes(const MspiX3dStageDesc* d);
-int mspi_x3d_stage_fwd(const MspiX3dStageDesc* d, const void* x, void* y, const void* wq, const void* wf, void* ws,
-                       mspi_stream_t stream);
-/* Diagnostic: while buf != NULL (device memory, 16 * nblocks * 256 uint64) the kernel records 100 MHz time stamps per workgroup,
- * block and phase (tools/x3d_stage_debug.py); NULL (the default) switches them off. */
-int mspi_x3d_stage_debug_stamps(void* buf);
-
-/* ------------------------------------------------------------------------------------
  * Max pooling, channels-last, -inf padding.
  * Replaces nn.MaxPool3d / MaxPool2d at model/model_utils.py:189,206;
  *   backbones/resnet.py:82; SlowFast/stem_helper.py:195-197; backbones/MViT.py:1403-1409.

@@ -93,14 +93,6 @@ class X3dAbDesc(C.Structure):
     ]
 
 
-class X3dStageDesc(C.Structure):
-    _fields_ = [
-        ("N", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-        ("C", C.c_int32), ("D", C.c_int32), ("F", C.c_int32),
-        ("nblocks", C.c_int32), ("se_mask", C.c_uint32),
-    ]
-
-
 class PermuteDesc(C.Structure):
     _fields_ = [("dims", C.c_int32 * 6), ("strides", C.c_int64 * 6), ("src_elems", C.c_int64)]
 
@@ -154,11 +146,6 @@ _SIGNATURES = {
     "mspi_x3d_ab_pool_rows": (C.c_int, [C.POINTER(X3dAbDesc)]),
     "mspi_x3d_ab_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "mspi_x3d_ab_fwd": (C.c_int, [C.POINTER(X3dAbDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
-    "mspi_x3d_stage_supported": (C.c_int, [C.POINTER(X3dStageDesc)]),
-    "mspi_x3d_stage_packed_bytes": (C.c_size_t, [C.POINTER(X3dStageDesc), C.POINTER(C.c_size_t)]),
-    "mspi_x3d_stage_ws_bytes": (C.c_size_t, [C.POINTER(X3dStageDesc)]),
-    "mspi_x3d_stage_fwd": (C.c_int, [C.POINTER(X3dStageDesc), _P, _P, _P, _P, _P, _P]),
-    "mspi_x3d_stage_debug_stamps": (C.c_int, [_P]),
     "mspi_mlp_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "mspi_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mspi_postprocess_workspace": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -269,42 +269,6 @@ class ResStage(HipModule):
     def blocks(self, p):
         return [getattr(self, "pathway{}_res{}".format(p, i)) for i in range(self.num_blocks[p])]
 
-    def _pack(self):
-        """Per pathway: the operands of the one-launch form of blocks 1..n-1 (X3D stages whose blocks after the first all
-        keep width and resolution), or None."""
-        out = []
-        for p in range(self.num_pathways):
-            blocks = self.blocks(p)[1:]
-            ok = blocks and all(isinstance(b.branch2, X3DTransform) and b.pk is None for b in blocks)
-            out.append(E.pack_x3d_stage([b.branch2.pk for b in blocks]) if ok else None)
-        return out
-
-    def _run_tail(self, p, x, blocks):
-        """Blocks 1..n-1 of pathway p: one persistent launch where the stage kernel applies (and, when autotuning, wins)."""
-        spk = self.pk[p]
-        if not E.x3d_stage_supported(x, spk):
-            for b in blocks:
-                x = b.run(x)
-            return x
-        key = ("x3d_stage", x.N, x.T, x.H, x.W, spk.C, spk.D, spk.nblocks)
-        use = E.X3D_STAGE["cache"].get(key)
-        if use is None:
-            use = E.X3D_STAGE["mode"] == "1"             # auto: only where it has been MEASURED faster on this shape
-            if E.X3D_STAGE["mode"] == "auto" and E.AUTOTUNE["on"] and not torch.cuda.is_current_stream_capturing():
-                def layers():
-                    y = x
-                    for b in blocks:
-                        y = b.run(y)
-                    return y
-                layers()                                 # tunes the per-layer tiles first
-                use = E.time_ms(lambda: E.x3d_stage(x, spk)) <= E.time_ms(layers)
-                E.X3D_STAGE["cache"][key] = use
-        if use:
-            return E.x3d_stage(x, spk)
-        for b in blocks:
-            x = b.run(x)
-        return x
-
     def run(self, xs, outs=None, pathways=None):
         """outs[p]: where pathway p's last block writes (a channel slice of a concat buffer).
         pathways: subset to compute."""
@@ -315,10 +279,7 @@ class ResStage(HipModule):
                 continue
             x = xs[p]
             blocks = self.blocks(p)
-            if outs is None and len(blocks) > 1 and self.pk[p] is not None:
-                x = self._run_tail(p, blocks[0].run(x), blocks[1:])
-            else:
-                for bi, b in enumerate(blocks):
-                    x = b.run(x, out=outs[p] if (outs is not None and bi == len(blocks) - 1) else None)
+            for bi, b in enumerate(blocks):
+                x = b.run(x, out=outs[p] if (outs is not None and bi == len(blocks) - 1) else None)
             out.append(x)
         return out

@@ -85,18 +85,6 @@ def _tune_conv(launch, key, candidates):
     return best
 
 
-def time_ms(fn, reps=3):
-    """HIP-event time of `reps` calls of fn on the current stream, after one untimed call (autotuning helper)."""
-    fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / reps
-
-
 # ----------------------------------------------------------------------------- per-launch timing
 class Profiler:
     """Per-launch HIP-event timing of the C-ABI calls, on the stream the kernels are launched on
@@ -542,107 +530,6 @@ def x3d_ab(x, pk, pool=False):
         check(lib.mspi_x3d_ab_fwd(C.byref(d), x.ptr, pk.wa.data_ptr(), pk.ba.data_ptr(), pk.wb.data_ptr(), pk.bb.data_ptr(),
                                   out.ptr, part.data_ptr() if pool else None, _stream()), "mspi_x3d_ab_fwd")
     return (out, part) if pool else out
-
-
-# ----------------------------------------------------------------------------- X3D res-stage as one persistent launch
-# MSPI_X3D_STAGE = 0 (never) | 1 (wherever the kernel covers the stage) | auto (default: with autotuning on, the stage kernel is
-# timed against the per-layer launches the first time a stage shape is seen and used where it won; otherwise per-layer).
-# The kernel's workgroups wait for each other (csrc/x3d_stage.hip): at most X3D_STAGE_MAX_INFLIGHT forwards may be in flight
-# on one GPU (two such grids fit a CU side by side); runtime.GraphPipeline switches the kernel off for deeper pipelines.
-X3D_STAGE = {"mode": _os.environ.get("MSPI_X3D_STAGE", "auto"), "max_inflight": 2, "cache": {}}
-
-
-class PackedX3dStage:
-    __slots__ = ("wq", "wf", "C", "D", "F", "nblocks", "se_mask")
-
-
-def _x3d_stage_desc(pk, N, T, H, W):
-    d = _lib.X3dStageDesc()
-    d.N, d.T, d.H, d.W = N, T, H, W
-    d.C, d.D, d.F, d.nblocks, d.se_mask = pk.C, pk.D, pk.F, pk.nblocks, pk.se_mask
-    return d
-
-
-def pack_x3d_stage(blocks):
-    """blocks: the packs of the stride-1 X3D blocks of one stage, in order -- dicts with "a" / "c" (PackedConv, f16x3), "b"
-    (PackedDw 3x3x3) and optionally "se" = (w1 [F, Ds], b1 [F], w2 [Ds, F], b2 [Ds]).  Returns the operands of
-    mspi_x3d_stage_fwd (layout: include/mspi_hip.h) or None when the blocks are outside the kernel's range."""
-    if not blocks or len(blocks) > 32:
-        return None
-    a0, b0, c0 = blocks[0]["a"], blocks[0]["b"], blocks[0]["c"]
-    C_, Ds = a0.cin_s, a0.cout_s
-    F = max([bk["se"][0].shape[0] for bk in blocks if "se" in bk] + [1])
-    for bk in blocks:
-        a, b, c = bk["a"], bk["b"], bk["c"]
-        if (a.prec != PREC_F16X3 or c.prec != PREC_F16X3 or a.k != (1, 1, 1) or c.k != (1, 1, 1) or a.stride != (1, 1, 1)
-                or c.stride != (1, 1, 1) or b.k != (3, 3, 3) or b.stride != (1, 1, 1) or b.pad != (1, 1, 1)
-                or a.cin_s != C_ or a.cin != C_ or c.cout_s != C_ or c.cout != C_ or a.cout_s != Ds or b.c_s != Ds or c.cin_s != Ds
-                or a.act != ACT_RELU or c.act != ACT_RELU or a.bias is None or c.bias is None
-                or ("se" in bk and bk["se"][0].shape[0] != F)):
-            return None
-    if C_ % 32:
-        return None
-    pk = PackedX3dStage()
-    pk.C, pk.D, pk.F, pk.nblocks = C_, b0.c, F, len(blocks)
-    pk.se_mask = sum(1 << i for i, bk in enumerate(blocks) if "se" in bk)
-    d = _x3d_stage_desc(pk, 1, 16, 7, 7)          # the packed sizes depend on C / D / F only
-    lib = _lib.load()
-    nf = C.c_size_t(0)
-    qbytes = lib.mspi_x3d_stage_packed_bytes(C.byref(d), C.byref(nf))
-    if not qbytes:
-        return None
-    fstride = (nf.value + 3) // 4 * 4
-    KSA, NA, KSC, NC = C_ // 16, (Ds + 31) // 32, (Ds + 15) // 16, C_ // 32
-    dev = a0.w.device
-
-    def frags(w, nch, ks):                         # [2, rows, ldw] f16 planes -> [ks][chunk][plane][lane][8]
-        pad = torch.zeros(2, nch * 32, ks * 16, dtype=torch.float16)
-        wc = w.cpu()
-        pad[:, : wc.shape[1], : min(wc.shape[2], ks * 16)] = wc[:, :, : ks * 16]
-        return pad.view(2, nch, 32, ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(-1)     # (ks, j, plane, lh, li, e)
-
-    wq = torch.empty(len(blocks), qbytes // 2, dtype=torch.float16)
-    wf = torch.zeros(len(blocks), fstride, dtype=torch.float32)
-    for i, bk in enumerate(blocks):
-        a, b, c = bk["a"], bk["b"], bk["c"]
-        wq[i] = torch.cat([frags(a.w, NA, KSA), frags(c.w, NC, KSC)])
-        o = 0
-        wf[i, o: o + Ds] = a.bias.cpu(); o += NA * 32
-        wf[i, o: o + C_] = c.bias.cpu(); o += C_
-        wf[i, o: o + Ds] = b.bias.cpu(); o += Ds
-        wf[i, o: o + 27 * Ds] = b.w.cpu().reshape(-1); o += 27 * Ds
-        if "se" in bk:
-            w1, b1, w2, b2 = bk["se"]
-            wf[i, o: o + F * Ds] = w1.cpu().reshape(-1)
-            wf[i, o + F * Ds: o + F * Ds + F] = b1.cpu()
-            wf[i, o + F * Ds + F: o + F * Ds + F + Ds * F] = w2.cpu().reshape(-1)
-            wf[i, o + F * Ds + F + Ds * F: o + F * Ds + F + Ds * F + Ds] = b2.cpu()
-        o += F * Ds + F + Ds * F + Ds
-        wf[i, o] = 1.0 / a.w_scale
-        wf[i, o + 1] = 1.0 / c.w_scale
-        assert o + 2 == nf.value
-    pk.wq, pk.wf = wq.contiguous().to(dev), wf.contiguous().to(dev)
-    return pk
-
-
-def x3d_stage_supported(x, pk):
-    return (pk is not None and X3D_STAGE["mode"] != "0" and isinstance(x, CL) and x.dense and x.ld == pk.C and x.C == pk.C
-            and bool(_lib.load().mspi_x3d_stage_supported(C.byref(_x3d_stage_desc(pk, x.N, x.T, x.H, x.W)))))
-
-
-def x3d_stage(x, pk):
-    """The stride-1 blocks of an X3D stage in one persistent launch (csrc/x3d_stage.hip); x: dense CL with C channels."""
-    lib = _lib.load()
-    _need_gpu(x.buf)
-    d = _x3d_stage_desc(pk, x.N, x.T, x.H, x.W)
-    out = alloc(x.N, x.T, x.H, x.W, pk.C, x.buf.device)
-    ws = torch.empty(lib.mspi_x3d_stage_ws_bytes(C.byref(d)), dtype=torch.uint8, device=x.buf.device)   # stream-ordered scratch
-    Ds = rup4(pk.D)
-    with _Timed("x3d_stage", 2.0 * x.M * pk.nblocks * (2 * pk.C + 27) * pk.D, 4.0 * x.M * pk.nblocks * (2 * pk.C + 4 * Ds),
-                "in=%s C=%d D=%d blocks=%d" % ((x.N, x.T, x.H, x.W), pk.C, pk.D, pk.nblocks)):
-        check(lib.mspi_x3d_stage_fwd(C.byref(d), x.ptr, out.ptr, pk.wq.data_ptr(), pk.wf.data_ptr(), ws.data_ptr(), _stream()),
-              "mspi_x3d_stage_fwd")
-    return out
 
 
 def _pad_vec(v, n):
