@@ -36,7 +36,10 @@ def parse():
     ap.add_argument("--swin-depths", type=int, nargs=4, default=None, help="Video-Swin stage depths (overrides --model's)")
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--wa", type=int, default=300, help="spectrogram columns (BASELINE: 300; reference default 111)")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-graph", "--eager", dest="no_graph", action="store_true",
+                    help="launch eagerly instead of replaying a hipGraph (the clip loop's default launch path)")
+    ap.add_argument("--no-eager-line", action="store_true", help="skip the short eager-launch measurement reported as `eager` beside "
+                    "the hipGraph number (single-GPU runs only)")
     ap.add_argument("--inflight", type=int, default=2, help="hipGraphs of the forward kept in flight (mspi_amd.runtime.GraphPipeline): "
                     "consecutive steps (batches) replay round-robin on this many streams, so the low-occupancy tail of one batch "
                     "overlaps the head of the next (each step is still one full forward of one batch; 1 = one batch at a time)")
@@ -81,6 +84,11 @@ if ARGS is not None and ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
 # before the HIP runtime initialises; multi-rank runs keep the default because RCCL's streams take queues too).
 if ARGS is not None and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("MSPI_BENCH_FORCE_DIST"):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+elif ARGS is not None:
+    # with a process group RCCL's own streams take hardware queues: one rank through the whole RCCL path on a one-GPU box
+    # (tools/dist_rehearsal.sh, profiles/r03_dist_rehearsal.txt): 4 queues 96.8 %, 5 queues 97.9 %, 6: 84.0 %, 8: 91.2 % of the
+    # single-process line; the stream-layout probe runs after init_process_group + the weight broadcast in every case
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -183,7 +191,7 @@ def dry_run(args, rank, world):
     """The launch contract without a GPU: rendezvous, barrier, K empty steps, max over ranks, one JSON line."""
     multi = world > 1
     if multi:
-        dist.init_process_group("gloo" if args.backend != "nccl" or not torch.cuda.is_available() else "nccl")
+        dist.init_process_group("gloo")          # the dry run never touches the GPU, whatever --backend says
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -369,6 +377,7 @@ def main():
 
     elapsed = timed(step, flush)
 
+    E.check_range()                               # f16x3 range guard: any GEMM result that left the window raises here
     ok = all(bool(torch.isfinite(o).all().item()) and abs(torch.logsumexp(o.flatten(1), 1)).max().item() < 1e-3 for o in outs)
     if depth > 1:                                 # every graph in flight computed the same maps
         ok = ok and all(torch.equal(outs[0], o) for o in outs[1:])
@@ -408,6 +417,22 @@ def main():
               "latency_ms_per_batch_with_postproc": round(1e3 * sorted(lat)[len(lat) // 2], 4)}
         del u8
     graph_mode = not args.no_graph
+    # The drop-in entry (mspi_amd/inference.py) launches EAGERLY by default (its hipGraph path stalls beside the loop's host
+    # work: DESIGN.md section 3, profiles/r03_clip_loop_pipeline.txt), so its model rate is put on record beside the graph's:
+    # the same forward, same resident inputs, launched call by call from Python on the three branch streams.
+    eager = None
+    if pipe and not multi and not args.no_eager_line:
+        ne = max(3, min(10, args.steps))
+        for _ in range(2):
+            model(clips, audio)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(ne):
+            model(clips, audio)
+        torch.cuda.synchronize()
+        el_e = time.perf_counter() - t1
+        eager = {"value": round(B * ne / el_e, 3), "unit": "clips/s", "ms_per_step": round(1e3 * el_e / ne, 4), "steps": ne,
+                 "launch": "eager: one Python call per kernel, three branch streams (the clip loop's default)"}
 
     if rank != 0:
         if multi:
@@ -436,6 +461,8 @@ def main():
     }
     if pp:
         line.update(pp)
+    if eager:
+        line["eager"] = eager
     if graph_mode:   # latency of ONE batch alone on the chip (no neighbouring batch in flight): median of 7 replays
         line["latency_ms_per_batch"] = lat_main
         line["saliency_map_ms_per_clip"] = round((pp["latency_ms_per_batch_with_postproc"] if pp else line["latency_ms_per_batch"]) / B, 4)

@@ -182,7 +182,9 @@ class X3DTransform(HipModule):
     def run(self, x, res, out=None):
         """res: skip tensor added before the final ReLU."""
         pk = self.pk
-        if pk["ab"] is not None and (FUSE_AB == "1" or x.W >= FUSE_MIN_W) and E.x3d_ab_supported(x, pk["ab"]):
+        # the fused kernel is built from `a`'s f16x3 planes: it follows that pack's first-sight range check
+        if pk["ab"] is not None and (FUSE_AB == "1" or x.W >= FUSE_MIN_W) and E.x3d_ab_supported(x, pk["ab"]) \
+                and E.range_check_input(pk["a"], x):
             if "se" in pk:
                 u, part = E.x3d_ab(x, pk["ab"], pool=True)
                 gate = E.se_gate(part, 1.0 / (u.T * u.H * u.W), *pk["se"])

@@ -389,6 +389,7 @@ namespace mspi {
 int launch_conv_ad(ConvArgs& a, long Ml, int force_bn, int* cfg, hipStream_t s);
 int launch_conv_ad8(ConvArgs& a, long Ml, int bn, int* cfg, hipStream_t s);
 int launch_conv_sp(ConvArgs& a, long Ml, int bn, int rows, int* cfg, hipStream_t s);
+int launch_conv_spr(ConvArgs& a, long Ml, int bn, int* cfg, hipStream_t s);   // conv_gemm_spr.hip
 }
 
 static thread_local int g_last_cfg = 0;
@@ -595,6 +596,34 @@ extern "C" int mspi_split_planes_fwd(const float* x, int64_t ldx, int64_t M, int
   return check_launch("mspi_split_planes_fwd");
 }
 
+namespace mspi {
+// the inverse hand-over: fp32 rows = hi + lo (22 bits of the value the producer split)
+__global__ __launch_bounds__(256) void join_planes_kernel(const _Float16* __restrict__ in, long ldi, long plane, float* __restrict__ y,
+                                                         long ldy, long M, int K4) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * K4) return;
+  const long m = idx / K4;
+  const int c = (int)(idx - m * K4) * 4;
+  const v4h h = *reinterpret_cast<const v4h*>(in + m * ldi + c);
+  const v4h l = *reinterpret_cast<const v4h*>(in + plane + m * ldi + c);
+  float4 v;
+  v.x = (float)h[0] + (float)l[0]; v.y = (float)h[1] + (float)l[1]; v.z = (float)h[2] + (float)l[2]; v.w = (float)h[3] + (float)l[3];
+  *reinterpret_cast<float4*>(y + m * ldy + c) = v;
+}
+}  // namespace mspi
+
+extern "C" int mspi_join_planes_fwd(const void* planes, int64_t ldi, int64_t plane, int64_t M, int32_t K, float* y, int64_t ldy,
+                                    mspi_stream_t stream) {
+  MSPI_REQUIRE(planes && y && M > 0 && K > 0 && (K & 3) == 0 && (ldi & 3) == 0 && (ldy & 3) == 0 && ldi >= K && ldy >= K &&
+                   plane >= M * ldi && aligned16(planes) && aligned16(y) && (plane & 7) == 0,
+               "mspi_join_planes_fwd: K / ldi / ldy multiples of 4, 16-B aligned pointers, plane >= M*ldi");
+  const long total = M * (K / 4);
+  MSPI_REQUIRE((total + 255) / 256 < (1L << 31), "mspi_join_planes_fwd: grid too large");
+  hipLaunchKernelGGL(mspi::join_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)planes, (long)ldi, (long)plane, y, (long)ldy, (long)M, K / 4);
+  return check_launch("mspi_join_planes_fwd");
+}
+
 extern "C" int mspi_gemm_sp_fwd(const MspiConvDesc* d, const void* x_planes, int64_t ldx, int64_t xplane, const float* w,
                                 const float* bias, const float* res, float* y, void* y_planes, int64_t ldys, int64_t yplane,
                                 mspi_stream_t stream) {
@@ -637,7 +666,11 @@ extern "C" int mspi_gemm_sp_fwd(const MspiConvDesc* d, const void* x_planes, int
     default: bn = d->Cout <= 64 ? 64 : (d->Cout % 192 == 0 ? 192 : 128); break;
   }
   int cfg = 0;
-  const int rc = launch_conv_sp(a, Ml, bn, rows, &cfg, (hipStream_t)stream);
+  // 15 / 17 / 18: A fragments global -> registers, deep weight ring (conv_gemm_spr.hip), 128 x {64, 128, 192}
+  const int rc = d->tile == 15 ? launch_conv_spr(a, Ml, 64, &cfg, (hipStream_t)stream)
+               : d->tile == 17 ? launch_conv_spr(a, Ml, 128, &cfg, (hipStream_t)stream)
+               : d->tile == 18 ? launch_conv_spr(a, Ml, 192, &cfg, (hipStream_t)stream)
+                               : launch_conv_sp(a, Ml, bn, rows, &cfg, (hipStream_t)stream);
   MSPI_REQUIRE(rc == 0, "mspi_gemm_sp_fwd: tile %d could not be launched", d->tile);
   g_last_cfg = cfg;
   return check_launch("mspi_gemm_sp_fwd");

@@ -106,10 +106,11 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__
   const int idx = (blockIdx.x * 256 + threadIdx.x) * 16;
   if (idx >= L) return;
   const float lo = mm[2 * n], hi = mm[2 * n + 1];
-  const float inv = hi - lo;
+  const float inv = hi > lo ? hi - lo : 1.f;        // a constant map quantises to 0 everywhere (the reference's 0/0 would be NaN -> 0 too)
   const float* yp = y + (long)n * L + idx;
   unsigned char* op = out + (long)n * L + idx;
-  if (idx + 16 <= L && (((long)n * L + idx) & 15) == 0) {
+  // the vector path needs the float4 loads AND the 16-byte store aligned: the real pointers are tested, not just the offset
+  if (idx + 16 <= L && ((reinterpret_cast<uintptr_t>(yp) | reinterpret_cast<uintptr_t>(op)) & 15u) == 0) {
     unsigned w[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -128,9 +129,12 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__
 
 using namespace mspi;
 
+// workspace: blurred [N*H*W] | resized [N*Ho*Wo] | part [N*2*nb] | mm [N*2] floats, every sub-buffer on a 16-byte boundary
+static size_t pp_r4(size_t floats) { return (floats + 3) / 4 * 4; }
+
 extern "C" size_t mspi_postprocess_workspace(int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo) {
   const size_t nb = ((size_t)Ho * Wo + 255) / 256;
-  return ((size_t)N * H * W + (size_t)N * Ho * Wo + (size_t)N * 2 * nb + (size_t)N * 2) * sizeof(float) + 64;
+  return (pp_r4((size_t)N * H * W) + pp_r4((size_t)N * Ho * Wo) + pp_r4((size_t)N * 2 * nb) + pp_r4((size_t)N * 2)) * sizeof(float) + 64;
 }
 
 extern "C" int mspi_postprocess_u8(const float* logmap, unsigned char* out, void* workspace, int32_t N, int32_t H, int32_t W,
@@ -150,11 +154,12 @@ extern "C" int mspi_postprocess_u8(const float* logmap, unsigned char* out, void
     init = true;
   }
   hipStream_t s = (hipStream_t)stream;
+  MSPI_REQUIRE(aligned16(workspace), "mspi_postprocess_u8: workspace must be 16-byte aligned");
   float* blurred = reinterpret_cast<float*>(workspace);
-  float* resized = blurred + (size_t)N * H * W;
+  float* resized = blurred + pp_r4((size_t)N * H * W);
   const int nb = (Ho * Wo + 255) / 256;
-  float* part = resized + (size_t)N * Ho * Wo;
-  float* mm = part + (size_t)N * 2 * nb;
+  float* part = resized + pp_r4((size_t)N * Ho * Wo);
+  float* mm = part + pp_r4((size_t)N * 2 * nb);
   hipLaunchKernelGGL(blur_exp_kernel, dim3((H * W + 255) / 256, N), dim3(256), 0, s, logmap, blurred, H, W);
   hipLaunchKernelGGL(resize_minmax_kernel, dim3(nb, N), dim3(256), 0, s, blurred, resized, H, W, Ho, Wo, part);
   hipLaunchKernelGGL(minmax_reduce_kernel, dim3(N), dim3(256), 0, s, part, nb, mm);

@@ -290,6 +290,13 @@ def alloc_sp(N, T, H, W, Cc, device):
     return SP(torch.empty(2 * N * T * H * W * Cc, dtype=torch.float16, device=device), N, T, H, W, Cc, Cc)
 
 
+def join_planes(sp):
+    """SP -> dense CL of fp32 rows (hi + lo)."""
+    out = alloc(sp.N, sp.T, sp.H, sp.W, sp.C, sp.buf.device)
+    check(_lib.load().mspi_join_planes_fwd(sp.ptr, sp.ld, sp.plane, sp.M, sp.C, out.ptr, out.ld, _stream()), "mspi_join_planes_fwd")
+    return out
+
+
 def from_rows(t2d):
     """Wrap a contiguous [M, C] tensor (C % 4 == 0) as a CL with N=M, T=H=W=1."""
     assert t2d.dim() == 2 and t2d.stride(1) == 1 and t2d.stride(0) % 4 == 0
@@ -397,7 +404,7 @@ def _pack_rowgemm(ws, k_s, n_s, dev):
 
 
 class PackedMlp:
-    __slots__ = ("w", "b1", "b2", "c", "hidden", "s1", "s2", "act")
+    __slots__ = ("w", "b1", "b2", "c", "hidden", "s1", "s2", "act", "src", "checked", "fallback")
 
 
 def _f16_scale(w):
@@ -448,7 +455,21 @@ def pack_mlp(fc1_w, fc1_b, fc2_w, fc2_b, out_scale=None, act=ACT_GELU, device=No
     p.b1 = fc1_b.detach().float().contiguous().to(dev)
     p.b2 = b2.contiguous().to(dev)
     p.c, p.hidden, p.act = c, hidden, act
+    # first-sight range check (mlp()): the layer pair as two GEMM packs, built from these when the check needs them
+    p.src, p.checked, p.fallback = (fc1_w, fc1_b, fc2_w, fc2_b, out_scale), False, None
     return p
+
+
+def _tuning():
+    return AUTOTUNE["on"] and RANGE_CHECK["on"] and DEFAULT_PREC == PREC_F16X3 and not torch.cuda.is_current_stream_capturing()
+
+
+def range_check_input(pk, x):
+    """First-sight range check of PackedConv `pk` on its input `x` (CL), for callers that bypass conv() with a fused kernel
+    built from the pack's f16x3 planes (X3D a + b).  Returns True while the pack is on the f16x3 path."""
+    if _tuning() and pk.prec == PREC_F16X3:
+        _range_check(pk, lambda: (x.as_rows()[:, : x.C] if x.dense else x.buf).abs().max(), "conv %s %d -> %d" % (pk.k, pk.cin, pk.cout))
+    return pk.prec == PREC_F16X3
 
 
 class PackedDw:
@@ -543,8 +564,13 @@ def _out_extent(T, H, W, k, s, p):
     return ((T + 2 * p[0] - k[0]) // s[0] + 1, (H + 2 * p[1] - k[1]) // s[1] + 1, (W + 2 * p[2] - k[2]) // s[2] + 1)
 
 
-# mspi_gemm_sp_fwd: 128 x {128,64,96,192,256}, 256 x {256,192,128}
-SP_TILES = (6, 7, 9, 10, 11, 12, 13, 14)
+# mspi_gemm_sp_fwd: 128 x {128,64,96,192,256}, 256 x {256,192,128}; 15/17/18 = 128 x {64,128,192} with the A fragments in
+# registers and a deep weight ring (conv_gemm_spr.hip; K/32 >= 5/3/2)
+SP_TILES = (6, 7, 9, 10, 11, 12, 13, 14, 15, 17, 18)
+
+
+def sp_tile_supported(tile, K):
+    return K // 32 >= {15: 5, 17: 3, 18: 2}.get(tile, 1)
 
 
 def _conv_sp(x, pk, out, res, act, tile, sp_out):
@@ -593,7 +619,7 @@ def _conv_sp(x, pk, out, res, act, tile, sp_out):
     elif AUTOTUNE["on"] and not torch.cuda.is_current_stream_capturing():
         choice = AUTOTUNE["cache"].get(key)
         if choice is None:
-            choice = _tune_conv(launch, key, [t for t in SP_TILES if t < 12 or M >= 4096])
+            choice = _tune_conv(launch, key, [t for t in SP_TILES if (t < 12 or t >= 15 or M >= 4096) and sp_tile_supported(t, x.C)])
     elif key in AUTOTUNE["cache"]:
         choice = AUTOTUNE["cache"][key]
     with _Timed("conv_gemm", 2.0 * M * pk.cin * pk.cout, 4.0 * (M * pk.cin + M * pk.cout * (2 if res is not None else 1) + pk.cout * pk.cin),
@@ -616,8 +642,10 @@ def conv(x, pk, out=None, res=None, gate=None, act=None, tile=None, sp_out=False
             _range_check(pk, lambda: x.buf[: x.M * x.ld].view(x.M, x.ld)[:, : x.C].abs().max(), "planes -> %dx%d" % (pk.cin, pk.cout))
         if pk.prec == PREC_F16X3:
             return _conv_sp(x, pk, out, res, act, tile, sp_out)
-        raise MspiError("conv: this layer was moved to the fp32 path by the range check; run the forward again "
-                        "(its producer now hands over fp32 rows)")
+        # The range check has moved this layer to the fp32 path while its producer had already emitted planes (from the next
+        # forward on the producer hands over fp32 rows: mlp_tail / layernorm_for_gemm look at the pack's precision): rebuild
+        # the rows (hi + lo = 22 bits of the value) and take the fp32 path for this one call.
+        x, sp_out = join_planes(x), False
     if tuning:
         _range_check(pk, (lambda: (x.as_rows()[:, : x.C] if x.dense else x.buf).abs().max()) if isinstance(x, CL) else (lambda: x.abs().max()),
                      "conv %s %d -> %d" % (pk.k, pk.cin, pk.cout))
@@ -840,7 +868,9 @@ def attention(qkv, B, Ntok, heads, hd, scale, out=None, biasT=None, maskT=None, 
     d.q_sH = d.k_sH = d.v_sH = hd
     d.q_sT = d.k_sT = d.v_sT = qkv.ld
     d.o_sB, d.o_sH, d.o_sT = rows_per_sample * out.ld, hd, out.ld
-    d.scale, d.prec = float(scale), DEFAULT_PREC
+    d.scale = float(scale)
+    d.prec = _attn_prec(("qkv", heads, hd, Ntok, d.nwin), lambda: qkv.as_rows()[:, :Cc].abs().max() * abs(float(scale)),
+                        lambda: qkv.as_rows()[:, Cc:].abs().max())
     base = qkv.ptr
     with _Timed("attention", 4.0 * B * heads * Ntok * Ntok * hd, 16.0 * B * Ntok * Cc, "B=%d h=%d N=%d d=%d" % (B, heads, Ntok, hd)):
         _attn_launch(lib, d, base, base + 4 * Cc, base + 8 * Cc, None,
@@ -850,6 +880,25 @@ def attention(qkv, B, Ntok, heads, hd, scale, out=None, biasT=None, maskT=None, 
 
 
 ATTN_PLANES = _os.environ.get("MSPI_ATTN_PLANES", "1") != "0"      # A/B switch: K / V split once per head (mspi_attn_fwd_ws)
+# f16x3 attention scales q by 64 and k, v by 16 before the split (csrc/attn.hip): |q * scale| >= 1023 or |k|, |v| >= 4094 is inf
+# in the hi half.  First sight of an attention shape while tuning: operands beyond a quarter of that move the SHAPE to the fp32
+# MFMA kernel for good (same contract as the GEMM packs' range check).
+ATTN_PREC = {}
+
+
+def _attn_prec(key, amax_q, amax_kv):
+    if DEFAULT_PREC != PREC_F16X3:
+        return DEFAULT_PREC
+    prec = ATTN_PREC.get(key)
+    if prec is None:
+        if not _tuning():
+            return PREC_F16X3
+        aq, akv = float(amax_q()), float(amax_kv())
+        bad = not (aq == aq and akv == akv) or aq >= 256.0 or akv >= 1024.0
+        prec = ATTN_PREC[key] = PREC_F32 if bad else PREC_F16X3
+        if bad:
+            RANGE_CHECK["moved"].append(("attention %s" % (key,), max(aq, akv)))
+    return prec
 
 
 def _attn_launch(lib, d, q, k, v, res, biasT, maskT, tok_idx, o, dev):
@@ -861,10 +910,26 @@ def _attn_launch(lib, d, q, k, v, res, biasT, maskT, tok_idx, o, dev):
         check(lib.mspi_attn_fwd(C.byref(d), q, k, v, res, biasT, maskT, tok_idx, o, _stream()), "mspi_attn_fwd")
 
 
-def mlp(x, pk, res=None, ln=None, eps=1e-6, out=None):
-    """out = res + fc2(act(fc1(LN(x)))) in one launch (mspi_mlp_fwd); ln = (gamma, beta) or None."""
+def mlp(x, pk, res=None, ln=None, eps=1e-6, out=None, split=None):
+    """out = res + fc2(act(fc1(LN(x)))) in one launch (mspi_mlp_fwd); ln = (gamma, beta) or None.
+    split: the same pair as two PackedConv (fc1 with the activation, fc2), if the caller has them -- used by the first-sight
+    range check (else built from the fused pack's sources)."""
     lib = _lib.load()
     _need_gpu(x.buf)
+    if pk.fallback is None and not pk.checked and _tuning():
+        # First sight of this fused pair while tuning: run it ONCE as LayerNorm + two GEMMs, whose packs go through conv()'s
+        # range check on their real inputs (fc1: the normalised rows, fc2: the activations).  If either leaves the f16x3
+        # window the pair stays unfused on the fp32 path for good; otherwise the fused kernel takes over from the next call.
+        pk.checked = True
+        if split is None:
+            w1, b1, w2, b2, osc = pk.src
+            split = (pack_conv(w1, b1, act=pk.act, device=pk.w.device), pack_conv(w2, b2, out_scale=osc, device=pk.w.device))
+        y = conv(conv(layernorm(x, ln[0], ln[1], eps) if ln is not None else x, split[0]), split[1], res=res, out=out)
+        if split[0].prec != PREC_F16X3 or split[1].prec != PREC_F16X3:
+            pk.fallback = split
+        return y
+    if pk.fallback is not None:
+        return conv(conv(layernorm(x, ln[0], ln[1], eps) if ln is not None else x, pk.fallback[0]), pk.fallback[1], res=res, out=out)
     if x.C != pk.c or not x.dense:
         raise MspiError("mlp: input has %d channels (dense=%s), packed for %d" % (x.C, x.dense, pk.c))
     if pk.w.device != x.buf.device:
@@ -965,7 +1030,8 @@ def mvit_attention(q, k, v, B, heads, hd, scale, q_thw, k_thw, Rh, Rw, Rt, out=N
     d.k_sB, d.k_sH, d.k_sT = heads * Nk * DA, Nk * DA, DA
     d.v_sB, d.v_sH, d.v_sT = Nk * v.ld, hd, v.ld
     d.o_sB, d.o_sH, d.o_sT = Nq * out.ld, hd, out.ld
-    d.scale, d.prec = 1.0, DEFAULT_PREC
+    d.scale = 1.0
+    d.prec = _attn_prec(("mvit", heads, hd, Nq, Nk), lambda: qa.abs().max(), lambda: torch.maximum(ka.abs().max(), v.buf.abs().max()))
     assert q.ld == out.ld and q.dense and out.dense   # residual pooling reads q with o's strides
     with _Timed("attention", 2.0 * B * heads * Nq * Nk * (DA + hd), 4.0 * B * heads * (Nq * (DA + 2 * hd) + Nk * (DA + hd)),
                 "B=%d h=%d Nq=%d Nk=%d d=%d+%d" % (B, heads, Nq, Nk, DA, hd)):

@@ -160,6 +160,7 @@ def process(model, frames, frame_idx, vname, img_size, audio_feature=None, args=
     else:
         pred = model(frames, **kw)[0]
     maps = E.postprocess_u8(pred, (img_size[1], img_size[0])).cpu().numpy()      # img_size is (W, H) as in cv2.resize
+    E.check_range(sync=False)                # range guard of the f16x3 GEMMs (the .cpu() above synchronised): raise, never write NaN-as-0 maps
     os.makedirs(os.path.join(args.save_path, vname), exist_ok=True)
     names = frame_idx if isinstance(frame_idx, (list, tuple)) else [frame_idx]
     _write_maps(maps, names, vname, args)
@@ -219,8 +220,7 @@ class _WindowRunner:
                 _write_maps(*out, args)
             self.pipe = GraphPipeline(self._fn(cached), [t.to(device) for t in inputs], depth=self.depth, layouts=3)
             self.key = key
-            idle = self.pipe.idle_streams(2)
-            self.pipe._copy_stream = idle[0]
+            idle = self.pipe.prepare(2)
             idle[1].wait_stream(torch.cuda.current_stream())
             self.loop_stream = idle[1]
         ticket = self.pipe.submit(*[t.to(device, non_blocking=True) for t in inputs])

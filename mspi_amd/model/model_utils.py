@@ -271,7 +271,7 @@ class ConvNextBlock(HipModule):
         pk = self.pk
         y = E.dwconv(E.dwconv(x, pk["dt"]), pk["ds"])
         if pk["fused"] is not None and y.M >= 4096:      # below that the two tiled GEMMs (split-K on the small maps) win
-            return E.mlp(y, pk["fused"], res=x, ln=pk["ln"], eps=1e-5, out=out)
+            return E.mlp(y, pk["fused"], res=x, ln=pk["ln"], eps=1e-5, out=out, split=(pk["p1"], pk["p2"]))
         return E.conv(E.conv(E.layernorm(y, *pk["ln"], 1e-5), pk["p1"]), pk["p2"], res=x, out=out)
 
 

@@ -33,6 +33,9 @@ def configure_hw_queues(n=6):   # 6: pure replay of two graphs (bench.py); 8: pl
     return True
 
 
+_CANDIDATES = []      # idle-queue probe streams, shared by every pipeline of the process
+
+
 class _Slot:
     __slots__ = ("stream", "graph", "inputs", "outs", "host", "done", "busy", "keep")
 
@@ -172,6 +175,8 @@ class GraphPipeline:
             s.done.synchronize()
             s.busy = False
             s.keep = None
+            from . import engine as E
+            E.check_range(sync=False)          # the f16x3 range guard: a pinned host word, valid behind the event just waited for
         return s.outs if len(s.outs) > 1 else s.outs[0]
 
     def idle_streams(self, k=1, candidates=10):
@@ -181,7 +186,16 @@ class GraphPipeline:
         tools/d2h_probe.py).  Which queues the runtime gave the graphs' branches is not exposed, so this measures: with all
         graphs replaying, a one-element kernel on each candidate; the quickest candidates sit on free queues.  Needs
         GPU_MAX_HW_QUEUES > the graphs' 3 * depth branches (configure_hw_queues(8) for depth 2)."""
-        cands = [torch.cuda.Stream() for _ in range(candidates)]
+        if any(s.busy for s in self.slots):
+            # the probe replays every slot's graph: with a batch in flight that would overwrite the outputs a caller is about
+            # to fetch (and `after` is not rerun).  Probe during set-up (prepare()) or on a drained pipeline.
+            raise RuntimeError("GraphPipeline.idle_streams(): batches in flight -- call prepare() before the first submit, or drain()")
+        # candidate streams are created ONCE per process: torch hands streams out of a 32-entry pool per device, and fresh
+        # candidates for every probe (plus the stream-layout trials) could wrap it and alias a "free" stream onto a slot's
+        global _CANDIDATES
+        if len(_CANDIDATES) < candidates:
+            _CANDIDATES += [torch.cuda.Stream() for _ in range(candidates - len(_CANDIDATES))]
+        cands = _CANDIDATES[:candidates]
         probe = torch.zeros(1, device=self.example[0].device)
         lat = []
         for c in cands:
@@ -201,13 +215,21 @@ class GraphPipeline:
         self.idle_latency_ms = [round(1e3 * lat[i], 3) for i in order]
         return [cands[i] for i in order[:k]]
 
+    def prepare(self, k=1):
+        """Pick the copy stream of fetch_host() (and k - 1 more idle streams, returned) while nothing is in flight: call
+        once after construction when host outputs will be fetched."""
+        idle = self.idle_streams(k)
+        self._copy_stream = idle[0]
+        return idle
+
     def fetch_host(self, ticket):
         s = self.slots[ticket]
         self.fetch(ticket)                                         # the replay has finished
         if s.host is None:
             s.host = tuple(torch.empty(o.shape, dtype=o.dtype, pin_memory=True) for o in s.outs)
-        if self._copy_stream is None:
-            self._copy_stream = self.idle_streams(1)[0]
+        if self._copy_stream is None:                              # no prepare(): probe now, on a drained pipeline
+            self.drain()
+            self.prepare()
         with torch.cuda.stream(self._copy_stream):
             for h, o in zip(s.host, s.outs):
                 h.copy_(o, non_blocking=True)

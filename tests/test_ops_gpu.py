@@ -557,6 +557,8 @@ def test_presplit_ln_gemm_gemm_chain(dev, M, C, Hd):
     _close(plain.buf.view(M, C), ref, 2e-5, "fp32-activation chain")
     for t1 in E.SP_TILES:
         for t2 in (E.SP_TILES if t1 == 6 else (10,)):
+            if not (E.sp_tile_supported(t1, C) and E.sp_tile_supported(t2, Hd)):
+                continue
             sp = E.layernorm(xcl, *ln, 1e-6, sp=True)
             assert isinstance(sp, E.SP) and sp.buf.dtype == torch.float16
             h = E.conv(sp, p1, sp_out=True, tile=t1)
@@ -724,3 +726,97 @@ def test_attention_planes_bit_identical(dev, B, H, N, D, win):
             E.ATTN_PLANES = True
     assert torch.equal(outs[0], outs[1])
 
+
+
+def test_range_check_moves_plane_consumer_in_mid_forward(dev):
+    """mlp_tail's split path: LN -> planes -> fc1 + GELU -> planes -> fc2.  fc2 is first seen AFTER fc1 has emitted planes; when
+    its input is beyond the f16x3 window (|h| >= 2^15) the range check moves it to fp32 in the middle of the forward: the call
+    completes (planes rebuilt as rows for this one forward) and is fp32-accurate; the next forward hands fc2 rows."""
+    from mspi_amd import engine as E
+    if E.DEFAULT_PREC != E.PREC_F16X3:
+        pytest.skip("f16x3 only")
+    g = torch.Generator().manual_seed(5)
+    M, C, Hd = 700, 256, 512
+    x = torch.randn(M, C, generator=g)
+    gam, bet = torch.ones(C), torch.zeros(C)
+    w1, b1 = torch.randn(Hd, C, generator=g) * (1.2e4 / math.sqrt(C)), torch.zeros(Hd)       # fc1 outputs up to ~5e4 (< 65504)
+    w2, b2 = torch.randn(C, Hd, generator=g) / (math.sqrt(Hd) * 1e4), torch.randn(C, generator=g) * 0.1
+    ln = F.layer_norm(x.double(), (C,), gam.double(), bet.double(), 1e-6)
+    ref = x.double() + F.linear(F.gelu(F.linear(ln, w1.double(), b1.double())), w2.double(), b2.double())
+    xcl = E.CL(x.to(dev).view(-1), 0, 1, 1, 1, M, C, C)
+    packed = ("split", E.pack_conv(w1, b1, act=E.ACT_GELU, device=dev), E.pack_conv(w2, b2, device=dev))
+    lnp = (gam.to(dev), bet.to(dev))
+    moved = len(E.RANGE_CHECK["moved"])
+    E.range_flag()
+    E.autotune(True)
+    try:
+        first = E.mlp_tail(xcl, packed, lnp, 1e-6, xcl).buf.view(M, C).cpu().double()
+        second = E.mlp_tail(xcl, packed, lnp, 1e-6, xcl).buf.view(M, C).cpu().double()
+    finally:
+        E.autotune(False)
+    assert packed[1].prec == E.PREC_F16X3 and packed[2].prec == E.PREC_F32 and len(E.RANGE_CHECK["moved"]) == moved + 1
+    E.check_range()
+    for y in (first, second):
+        assert (y - ref).abs().max().item() < 3e-6 * ref.abs().max().item()
+
+
+def test_fused_mlp_first_sight_range_check(dev):
+    """The fused LN -> fc1 -> GELU -> fc2 kernel (mspi_mlp_fwd) has no fp32 form: on first sight while tuning the pair runs
+    once as LayerNorm + two GEMMs through conv()'s range check; a hidden activation beyond 2^15 keeps the pair unfused on the
+    fp32 path (results fp32-accurate), an in-range pair goes fused from the second call on."""
+    from mspi_amd import engine as E
+    if not E.mlp_supported(96, 384):
+        pytest.skip("fused MLP not available in this configuration")
+    g = torch.Generator().manual_seed(6)
+    M, C, Hd = 4200, 96, 384
+    x = torch.randn(M, C, generator=g)
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    xcl = E.CL(x.to(dev).view(-1), 0, 1, 1, 1, M, C, C)
+    lnp = (gam.to(dev), bet.to(dev))
+    for scale, want_fallback in ((1.0, False), (1.5e4, True)):
+        w1, b1 = torch.randn(Hd, C, generator=g) * (scale / math.sqrt(C)), torch.randn(Hd, generator=g) * 0.1
+        w2, b2 = torch.randn(C, Hd, generator=g) / (math.sqrt(Hd) * scale), torch.randn(C, generator=g) * 0.1
+        ln = F.layer_norm(x.double(), (C,), gam.double(), bet.double(), 1e-6)
+        ref = x.double() + F.linear(F.gelu(F.linear(ln, w1.double(), b1.double())), w2.double(), b2.double())
+        pm = E.pack_mlp(w1, b1, w2, b2, device=dev)
+        E.range_flag()
+        E.autotune(True)
+        try:
+            with E.Profiler() as prof:
+                y1 = E.mlp(xcl, pm, res=xcl, ln=lnp, eps=1e-6).buf.view(M, C).cpu().double()
+                y2 = E.mlp(xcl, pm, res=xcl, ln=lnp, eps=1e-6).buf.view(M, C).cpu().double()
+        finally:
+            E.autotune(False)
+        names = [r[0] for r in prof.records]
+        assert (pm.fallback is not None) == want_fallback
+        assert ("mlp_fused" in names) == (not want_fallback)
+        E.check_range()
+        for y in (y1, y2):
+            assert (y - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
+def test_attention_first_sight_moves_a_shape_to_fp32(dev):
+    """f16x3 attention scales q by 64 before its split: |q * scale| ~ 2e3 is inf in the hi half.  First sight while tuning moves
+    that SHAPE to the fp32 MFMA kernel; the result matches fp64."""
+    from mspi_amd import engine as E
+    if E.DEFAULT_PREC != E.PREC_F16X3:
+        pytest.skip("f16x3 only")
+    g = torch.Generator().manual_seed(7)
+    B, Ntok, heads, hd = 2, 77, 2, 32
+    qkv = torch.randn(B * Ntok, 3 * heads * hd, generator=g)
+    qkv[:, : heads * hd] *= 4e3                       # q
+    qkv[:, heads * hd: 2 * heads * hd] *= 1e-3        # k: keeps the logits moderate
+    scale = 0.5
+    q, k, v = [t.reshape(B, Ntok, heads, hd).permute(0, 2, 1, 3).double() for t in qkv.chunk(3, 1)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).permute(0, 2, 1, 3).reshape(B * Ntok, heads * hd)
+    cl = E.CL(qkv.to(dev).view(-1), 0, B, 1, 1, Ntok, 3 * heads * hd, 3 * heads * hd)
+    key = ("qkv", heads, hd, Ntok, 0)
+    E.ATTN_PREC.pop(key, None)
+    E.autotune(True)
+    try:
+        out = E.attention(cl, B, Ntok, heads, hd, scale).buf.view(B * Ntok, heads * hd).cpu().double()
+    finally:
+        E.autotune(False)
+    assert E.ATTN_PREC[key] == E.PREC_F32
+    E.ATTN_PREC.pop(key, None)
+    assert (out - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
