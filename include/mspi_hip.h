@@ -402,6 +402,9 @@ int mspi_split_planes_fwd(const float* x, int64_t ldx, int64_t M, int32_t K, voi
 /* planes -> fp32 rows (hi + lo): for a consumer that was moved off the f16x3 path after its producer had emitted planes */
 int mspi_join_planes_fwd(const void* planes, int64_t ldi, int64_t plane, int64_t M, int32_t K, float* y, int64_t ldy,
                          mspi_stream_t stream);
+/* Diagnostic: while buf != NULL (device memory, 64 uint64 per workgroup) mspi_gemm_sp_fwd's tile codes 15 / 17 / 18 record 100 MHz
+ * time stamps of one trip of their K loop; NULL (the default) switches them off. */
+int mspi_debug_stamps(void* buf);
 int mspi_gemm_sp_fwd(const MspiConvDesc* d, const void* x_planes, int64_t ldx, int64_t xplane, const float* w,
                      const float* bias, const float* res, float* y, void* y_planes, int64_t ldys, int64_t yplane,
                      mspi_stream_t stream);

@@ -390,6 +390,7 @@ int launch_conv_ad(ConvArgs& a, long Ml, int force_bn, int* cfg, hipStream_t s);
 int launch_conv_ad8(ConvArgs& a, long Ml, int bn, int* cfg, hipStream_t s);
 int launch_conv_sp(ConvArgs& a, long Ml, int bn, int rows, int* cfg, hipStream_t s);
 int launch_conv_spr(ConvArgs& a, long Ml, int bn, int* cfg, hipStream_t s);   // conv_gemm_spr.hip
+extern unsigned long long* g_spr_stamps;
 }
 
 static thread_local int g_last_cfg = 0;
@@ -623,6 +624,10 @@ extern "C" int mspi_join_planes_fwd(const void* planes, int64_t ldi, int64_t pla
                      (const _Float16*)planes, (long)ldi, (long)plane, y, (long)ldy, (long)M, K / 4);
   return check_launch("mspi_join_planes_fwd");
 }
+
+// diagnostic: while buf != NULL (device memory, 64 uint64 per workgroup) the tile-code-15/17/18 GEMM records 100 MHz time stamps
+// of one trip of its K loop (tools/spr_stamps.py)
+extern "C" int mspi_debug_stamps(void* buf) { mspi::g_spr_stamps = (unsigned long long*)buf; return MSPI_OK; }
 
 extern "C" int mspi_gemm_sp_fwd(const MspiConvDesc* d, const void* x_planes, int64_t ldx, int64_t xplane, const float* w,
                                 const float* bias, const float* res, float* y, void* y_planes, int64_t ldys, int64_t yplane,

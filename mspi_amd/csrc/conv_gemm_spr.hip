@@ -13,6 +13,7 @@
 // COUNTED vmcnt (loads and LDS-DMA retire in issue order) + raw s_barrier.  Same staging layout, swizzle, K order and epilogue as
 // conv_gemm_dma_kernel: results are bit-identical to tile codes 6 .. 14.
 #include "conv_common.h"
+#include <stdlib.h>
 
 namespace mspi {
 
@@ -44,7 +45,11 @@ __global__ __launch_bounds__(256, 2) void gemm_spr_kernel(const ConvArgs p) {
   // A fragments: row m0 + wave*32 + li (rows past M repeat the last row; their results are dropped), 16 halves from k0 + 16 lh
   int arow = m0 + wave * 32 + li;
   if (arow >= p.M) arow = p.M - 1;
-  const _Float16* ah_p = p.xs + (long)arow * p.ldxs + 16 * lh;
+  // p.dbg & 128 (MSPI_SPR_FAKE=1, timing experiment only, results are garbage): the ACCESS PATTERN of a fragment-major plane
+  // layout -- every load instruction reads 1 KB of contiguous memory -- on the row-major data
+  const bool fake = p.dbg & 128;
+  const long fk8 = p.ldxs / 8;
+  const _Float16* ah_p = fake ? p.xs + (((long)(arow >> 5) * fk8 + lh) * 32 + li) * 8 : p.xs + (long)arow * p.ldxs + 16 * lh;
   const _Float16* al_p = ah_p + p.xplane;
   // weight DMA: plane chunks (i*4+wave)*64 + lane: row r = q/4, slot q%4, segment = slot ^ ((r>>2)&3)   (as conv_gemm_ad.hip)
   const _Float16* wh = reinterpret_cast<const _Float16*>(p.w);
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void gemm_spr_kernel(const ConvArgs p) {
   for (int i = 0; i < HBI; ++i) {
     const int n = n0 + (i * 4 + wave) * 16 + (lane >> 2);
     wok[i] = n < p.Cout;
-    wsrc[i] = wh + (long)(wok[i] ? n : 0) * p.ldw + b_seg * 8;
+    wsrc[i] = fake ? wh + ((long)((n0 >> 4) + i * 4 + wave) * (p.ldw / 32)) * 512 + lane * 8 : wh + (long)(wok[i] ? n : 0) * p.ldw + b_seg * 8;
   }
 
   // The A loads are inline asm: the compiler's own wait analysis merges the prologue's and the back edge's scoreboards at the loop
@@ -69,17 +74,20 @@ __global__ __launch_bounds__(256, 2) void gemm_spr_kernel(const ConvArgs p) {
     unsigned char* base_ = smem + (slot_) * STAGE;                                                                       \
     _Pragma("unroll") for (int i_ = 0; i_ < HBI; ++i_) {                                                                 \
       const bool ok_ = (live_) && wok[i_];                                                                               \
-      const void* s_hi_ = ok_ ? (const void*)(wsrc[i_] + (k0_)) : (const void*)g_zero16_spr;                             \
-      const void* s_lo_ = ok_ ? (const void*)(wsrc[i_] + wplane + (k0_)) : (const void*)g_zero16_spr;                    \
+      const long kw_ = fake ? (long)(k0_) * 16 : (long)(k0_);                                                            \
+      const void* s_hi_ = ok_ ? (const void*)(wsrc[i_] + kw_) : (const void*)g_zero16_spr;                               \
+      const void* s_lo_ = ok_ ? (const void*)(wsrc[i_] + wplane + kw_) : (const void*)g_zero16_spr;                      \
       __builtin_amdgcn_global_load_lds(s_hi_, (lds_void_r*)(base_ + (i_ * 4 + wave) * 1024), 16, 0, 0);                  \
       __builtin_amdgcn_global_load_lds(s_lo_, (lds_void_r*)(base_ + P_BYTES + (i_ * 4 + wave) * 1024), 16, 0, 0);        \
     }                                                                                                                    \
-    const _Float16* pa_ = (live_) ? ah_p + (k0_) : reinterpret_cast<const _Float16*>(g_zero16_spr) - 8;                  \
-    const _Float16* pb_ = (live_) ? al_p + (k0_) : reinterpret_cast<const _Float16*>(g_zero16_spr) - 8;                  \
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ah[slot_][0]) : "v"((live_) ? pa_ : pa_ + 8) : "memory");     \
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ah[slot_][1]) : "v"(pa_ + 8) : "memory");                     \
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(al[slot_][0]) : "v"((live_) ? pb_ : pb_ + 8) : "memory");     \
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(al[slot_][1]) : "v"(pb_ + 8) : "memory");                     \
+    const long sub1_ = fake ? 512 : 8;                      /* halves from the sub 0 to the sub 1 fragment */             \
+    const long ka_ = fake ? (long)(k0_) * 32 : (long)(k0_);                                                              \
+    const _Float16* pa_ = (live_) ? ah_p + ka_ : reinterpret_cast<const _Float16*>(g_zero16_spr);                        \
+    const _Float16* pb_ = (live_) ? al_p + ka_ : reinterpret_cast<const _Float16*>(g_zero16_spr);                        \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ah[slot_][0]) : "v"(pa_) : "memory");                         \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ah[slot_][1]) : "v"((live_) ? pa_ + sub1_ : pa_) : "memory"); \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(al[slot_][0]) : "v"(pb_) : "memory");                         \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(al[slot_][1]) : "v"((live_) ? pb_ + sub1_ : pb_) : "memory"); \
   } while (0)
 
   v16f acc[TN];
@@ -117,34 +125,35 @@ __global__ __launch_bounds__(256, 2) void gemm_spr_kernel(const ConvArgs p) {
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
   } while (0)
 
-  // Steady state: NST steps per trip, NO branch inside a trip -- every step waits for its own data with NST - 2 newer steps
+  // NST steps per trip, NO branch inside a trip -- every step waits for its own data with NST - 2 newer steps
   // still in flight, passes the barrier (everybody's step `it` has landed, everybody is done with step it - 1), refills the
   // slot of step it - 1 with step it + NST - 1 and computes.  (With `if (it < nk)` around the steps the accumulators went
   // through PHI copies behind every MFMA group.)
-  int it0 = 0;
+  // K is processed in whole trips: the steps past its end were issued from the zero page (zero weights, zero activations) and add
+  // nothing -- a peeled, conditional tail would put the asynchronously loaded fragment registers through PHI copies at its joins,
+  // i.e. copy them before their data has landed.
+  // diagnostic stamps (mspi_debug_stamps, tools/spr_stamps.py): p.ws != NULL only then.  One lane per workgroup, the second trip.
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(p.ws);
+#define SPR_STAMP(i_)                                                                                                   \
+  do {                                                                                                                  \
+    if (stamps && tid == 0 && it0 == NST) stamps[(long)blockIdx.x * 64 + u * 4 + (i_)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 #pragma unroll 1
-  for (; it0 + NST <= nk; it0 += NST) {
+  for (int it0 = 0; it0 < nk; it0 += NST) {
 #pragma unroll
     for (int u = 0; u < NST; ++u) {
+      SPR_STAMP(0);
       wait_vmcnt<VPS * (NST - 2)>();
+      SPR_STAMP(1);
       __builtin_amdgcn_s_barrier();
+      SPR_STAMP(2);
       SPR_ISSUE((u + NST - 1) % NST, (it0 + u + NST - 1) * BK, it0 + u + NST - 1 < nk);
       __builtin_amdgcn_sched_barrier(0);         // the loads are issued HERE (the scheduler would sink them below the MFMAs)
+      SPR_STAMP(3);
       SPR_COMPUTE(u);
     }
   }
-  // the last nk % NST steps (nothing real is left to issue)
-  const int rem = nk - it0;
-#pragma unroll
-  for (int v = 0; v < NST - 1; ++v) {
-    if (v < rem) {
-      wait_vmcnt<VPS * (NST - 2)>();
-      __builtin_amdgcn_s_barrier();
-      SPR_ISSUE((v + NST - 1) % NST, 0, false);
-      __builtin_amdgcn_sched_barrier(0);
-      SPR_COMPUTE(v);
-    }
-  }
+#undef SPR_STAMP
   wait_vmcnt<0>();                               // the zero-page loads of the last steps
 #undef SPR_COMPUTE
 #undef SPR_ISSUE
@@ -212,7 +221,12 @@ __global__ __launch_bounds__(256, 2) void gemm_spr_kernel(const ConvArgs p) {
 }
 
 // tile codes 15 / 17 / 18: 128 x {64, 128, 192}; returns -100 when the shape is outside the kernel (few k-steps)
+unsigned long long* g_spr_stamps = nullptr;   // mspi_debug_stamps
+
 int launch_conv_spr(ConvArgs& a, long Ml, int bn, int* cfg, hipStream_t s) {
+  a.ws = reinterpret_cast<float*>(g_spr_stamps);
+  static const int fake = getenv("MSPI_SPR_FAKE") ? atoi(getenv("MSPI_SPR_FAKE")) : 0;
+  if (fake) a.dbg |= 128;
   const int nst = bn == 64 ? 6 : (bn == 128 ? 4 : 3);
   if (a.ldw / BK < nst - 1) return -100;
   a.tiles_n = (int)((a.Cout + bn - 1) / bn);
