@@ -138,7 +138,6 @@ _SIGNATURES = {
                                          C.c_int32, C.c_int32, C.c_int32, _P]),
     "mspi_split_planes_fwd": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int64, _P]),
     "mspi_join_planes_fwd": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _P, C.c_int64, _P]),
-    "mspi_debug_stamps": (C.c_int, [_P]),
     "mspi_gemm_sp_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, _P]),
     "mspi_saliency_metrics": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mspi_rowgemm_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),

@@ -389,8 +389,6 @@ namespace mspi {
 int launch_conv_ad(ConvArgs& a, long Ml, int force_bn, int* cfg, hipStream_t s);
 int launch_conv_ad8(ConvArgs& a, long Ml, int bn, int* cfg, hipStream_t s);
 int launch_conv_sp(ConvArgs& a, long Ml, int bn, int rows, int* cfg, hipStream_t s);
-int launch_conv_spr(ConvArgs& a, long Ml, int bn, int* cfg, hipStream_t s);   // conv_gemm_spr.hip
-extern unsigned long long* g_spr_stamps;
 }
 
 static thread_local int g_last_cfg = 0;
@@ -625,10 +623,6 @@ extern "C" int mspi_join_planes_fwd(const void* planes, int64_t ldi, int64_t pla
   return check_launch("mspi_join_planes_fwd");
 }
 
-// diagnostic: while buf != NULL (device memory, 64 uint64 per workgroup) the tile-code-15/17/18 GEMM records 100 MHz time stamps
-// of one trip of its K loop (tools/spr_stamps.py)
-extern "C" int mspi_debug_stamps(void* buf) { mspi::g_spr_stamps = (unsigned long long*)buf; return MSPI_OK; }
-
 extern "C" int mspi_gemm_sp_fwd(const MspiConvDesc* d, const void* x_planes, int64_t ldx, int64_t xplane, const float* w,
                                 const float* bias, const float* res, float* y, void* y_planes, int64_t ldys, int64_t yplane,
                                 mspi_stream_t stream) {
@@ -671,11 +665,7 @@ extern "C" int mspi_gemm_sp_fwd(const MspiConvDesc* d, const void* x_planes, int
     default: bn = d->Cout <= 64 ? 64 : (d->Cout % 192 == 0 ? 192 : 128); break;
   }
   int cfg = 0;
-  // 15 / 17 / 18: A fragments global -> registers, deep weight ring (conv_gemm_spr.hip), 128 x {64, 128, 192}
-  const int rc = d->tile == 15 ? launch_conv_spr(a, Ml, 64, &cfg, (hipStream_t)stream)
-               : d->tile == 17 ? launch_conv_spr(a, Ml, 128, &cfg, (hipStream_t)stream)
-               : d->tile == 18 ? launch_conv_spr(a, Ml, 192, &cfg, (hipStream_t)stream)
-                               : launch_conv_sp(a, Ml, bn, rows, &cfg, (hipStream_t)stream);
+  const int rc = launch_conv_sp(a, Ml, bn, rows, &cfg, (hipStream_t)stream);
   MSPI_REQUIRE(rc == 0, "mspi_gemm_sp_fwd: tile %d could not be launched", d->tile);
   g_last_cfg = cfg;
   return check_launch("mspi_gemm_sp_fwd");

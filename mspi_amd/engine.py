@@ -564,13 +564,8 @@ def _out_extent(T, H, W, k, s, p):
     return ((T + 2 * p[0] - k[0]) // s[0] + 1, (H + 2 * p[1] - k[1]) // s[1] + 1, (W + 2 * p[2] - k[2]) // s[2] + 1)
 
 
-# mspi_gemm_sp_fwd: 128 x {128,64,96,192,256}, 256 x {256,192,128}; 15/17/18 = 128 x {64,128,192} with the A fragments in
-# registers and a deep weight ring (conv_gemm_spr.hip; K/32 >= 5/3/2)
-SP_TILES = (6, 7, 9, 10, 11, 12, 13, 14, 15, 17, 18)
-
-
-def sp_tile_supported(tile, K):
-    return K // 32 >= {15: 5, 17: 3, 18: 2}.get(tile, 1)
+# mspi_gemm_sp_fwd: 128 x {128,64,96,192,256}, 256 x {256,192,128}
+SP_TILES = (6, 7, 9, 10, 11, 12, 13, 14)
 
 
 def _conv_sp(x, pk, out, res, act, tile, sp_out):
@@ -619,7 +614,7 @@ def _conv_sp(x, pk, out, res, act, tile, sp_out):
     elif AUTOTUNE["on"] and not torch.cuda.is_current_stream_capturing():
         choice = AUTOTUNE["cache"].get(key)
         if choice is None:
-            choice = _tune_conv(launch, key, [t for t in SP_TILES if (t < 12 or t >= 15 or M >= 4096) and sp_tile_supported(t, x.C)])
+            choice = _tune_conv(launch, key, [t for t in SP_TILES if t < 12 or M >= 4096])
     elif key in AUTOTUNE["cache"]:
         choice = AUTOTUNE["cache"][key]
     with _Timed("conv_gemm", 2.0 * M * pk.cin * pk.cout, 4.0 * (M * pk.cin + M * pk.cout * (2 if res is not None else 1) + pk.cout * pk.cin),
