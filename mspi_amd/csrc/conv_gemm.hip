@@ -16,7 +16,12 @@
 namespace mspi {
 
 constexpr int LDK = 36;  // padded LDS row (floats): 144 B keeps 16-B alignment, kills b128 conflicts
-constexpr int LDH = 40;  // F16X3: padded LDS row (halves): 80 B rows -> 16 distinct 16-B slots per b128 lane group
+constexpr int LDH = 32;  // F16X3: LDS row (halves): 64 B = four 16-B slots, slot s of row r stored at s ^ ((r >> 2) & 3) -- the
+                         // LDS-DMA kernels' swizzle (0.000 measured bank conflicts on their ds_read_b128).  Round 1-2 padded the rows
+                         // to 80 B instead: conflict-free for the 16-B fragment reads, but the 8-B hi / lo staging writes of two
+                         // neighbouring rows then overlapped in 4 of 32 banks (SQ_LDS_BANK_CONFLICT 0.29-0.36 of the LDS cycles).
+                         // At a 64-B pitch a 16-lane group of 8-B writes is two whole rows = all 32 banks once.
+__device__ __forceinline__ int swz16(int row, int slot) { return (slot ^ ((row >> 2) & 3)) << 3; }   // halves
 
 enum { LOAD_V4 = 0, LOAD_S = 1 };
 
@@ -228,15 +233,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
           hi[e] = h; lo[e] = l;
         }
         if (p.dbg & 1) lo = hi;
-        *reinterpret_cast<v4h*>(&Ah[(rbase + RP * i) * LDH + kv * 4]) = hi;
-        *reinterpret_cast<v4h*>(&Al[(rbase + RP * i) * LDH + kv * 4]) = lo;
+        const int r = rbase + RP * i;
+        const int o = r * LDH + swz16(r, kv >> 1) + (kv & 1) * 4;
+        *reinterpret_cast<v4h*>(&Ah[o]) = hi;
+        *reinterpret_cast<v4h*>(&Al[o]) = lo;
       }
 #pragma unroll
       for (int i = 0; i < HB; ++i) {
         const int r = hrow + HR * i;
         if (r < BN) {
-          *reinterpret_cast<uint4*>(&Bh[r * LDH + hseg * 8]) = rbh[i];
-          *reinterpret_cast<uint4*>(&Bl[r * LDH + hseg * 8]) = rbl[i];
+          *reinterpret_cast<uint4*>(&Bh[r * LDH + swz16(r, hseg)]) = rbh[i];
+          *reinterpret_cast<uint4*>(&Bl[r * LDH + swz16(r, hseg)]) = rbl[i];
         }
       }
     }
@@ -277,13 +284,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
       v8h ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int o = ((wm * TM + i) * 32 + li) * LDH + kh * 16 + lh * 8;
+        const int r = (wm * TM + i) * 32 + li;
+        const int o = r * LDH + swz16(r, kh * 2 + lh);
         ah[i] = *reinterpret_cast<const v8h*>(&Ah[o]);
         al[i] = *reinterpret_cast<const v8h*>(&Al[o]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int o = ((wn * TN + j) * 32 + li) * LDH + kh * 16 + lh * 8;
+        const int r = (wn * TN + j) * 32 + li;
+        const int o = r * LDH + swz16(r, kh * 2 + lh);
         bh[j] = *reinterpret_cast<const v8h*>(&Bh[o]);
         bl[j] = *reinterpret_cast<const v8h*>(&Bl[o]);
       }
