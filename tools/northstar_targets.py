@@ -108,6 +108,12 @@ out["mvitv2s_attention_batch8"] = {"launches_per_forward": a["calls"] // 3, "ms_
                                    "frac_of_mfma_peak_algorithmic": round(tf / F16_PEAK, 4),
                                    "mfma_pipe_frac": round(3 * tf / F16_PEAK, 4), "target": 0.40,
                                    "dtype": "f16x3 split products (fp32-accurate), fp32 accumulate"}
+# The figure above counts the padded / augmented columns the kernel really multiplies (head dim 96 -> 128 / 144 for Q K^T).  On
+# SURVEY 8d's own count -- 29.4 GFLOP per clip for QK^T + PV + relative positions (backbones/MViT.py:1261-1290) -- the USEFUL rate:
+USEFUL_GFLOP_PER_CLIP = 29.4
+useful_tf = B * USEFUL_GFLOP_PER_CLIP / (a["ms"] / 3)            # GFLOP / ms = TFLOP/s
+out["mvitv2s_attention_batch8"].update({"useful_GFLOP_per_clip": USEFUL_GFLOP_PER_CLIP, "useful_TFLOPs": round(useful_tf, 1),
+                                        "useful_mfma_pipe_frac": round(3 * useful_tf / F16_PEAK, 4)})
 per = {}
 for name, fl, by, e0, e1, det in prof.records:
     if name == "attention":

@@ -2,7 +2,7 @@
 # Round profile on the GPU box: bench line, rocprofv3 kernel trace of the same command, HBM counter passes.
 # usage: tools/profile_round.sh <tag>      (writes gpurun_out/prof_<tag>/...)
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -21,8 +21,16 @@ rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o r --output-format csv -- python3
 echo "write done"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_mfma -o r --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-graph --tune-cache $CACHE --no-cpu-baseline --no-roofline > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err
 echo "mfma done"
+# the north star's second kernel target is measured on ITS workload: MViTv2-S attention
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_mfma_mvit -o r --output-format csv -- python3 bench.py --model mvitv2s --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline > $OUT/pmc_mfma_mvit.json 2> $OUT/pmc_mfma_mvit.err
+echo "mfma (mvitv2s) done"
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_lds -o r --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-graph --tune-cache $CACHE --no-cpu-baseline --no-roofline > $OUT/pmc_lds.json 2> $OUT/pmc_lds.err
+echo "lds done"
 python3 profiles/summarize.py $OUT $TAG > $OUT/summary.log 2>&1 || true
 python3 tools/mfma_busy_summary.py $OUT/pmc_mfma "x3dl+audio B=8 (bench.py --no-graph)" > profiles/${TAG}_mfma_busy.csv || true
+python3 tools/mfma_busy_summary.py $OUT/pmc_mfma_mvit "mvitv2s+audio B=8 (bench.py --model mvitv2s --no-graph)" | tail -n +2 >> profiles/${TAG}_mfma_busy.csv || true
+python3 tools/lds_conflict_summary.py $OUT/pmc_lds "x3dl+audio B=8 (bench.py --no-graph)" > profiles/${TAG}_lds_conflicts.csv || true
+python3 tools/northstar_targets.py > profiles/${TAG}_northstar.json 2> $OUT/northstar.err || true
 cp $OUT/bench.json profiles/${TAG}_bench.json; cp $OUT/bench_under_rocprof.json profiles/${TAG}_bench_under_rocprof.json
 cp $OUT/bench_under_rocprof_serial.json profiles/${TAG}_bench_under_rocprof_streams0.json
 for d in trace trace_serial; do f=$(find $OUT/$d -name "*_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f profiles/${TAG}_rocprofv3_kernel_stats$([ $d = trace_serial ] && echo _streams0).csv; done
