@@ -391,8 +391,7 @@ int mspi_resize_norm_fwd(const unsigned char* rgb, int32_t Hin, int32_t Win, uns
  * elements later; hi = f16(x), lo = f16(x - hi) -- the same split the kernels otherwise do in registers, so results are
  * bit-identical).  mspi_gemm_sp_fwd is the dense (1x1x1 / nn.Linear) GEMM on such planes: both operands then go
  * HBM -> LDS -> MFMA with no conversion work in the loop.  d: as for mspi_conv_fwd with C % 32 == 0, ldw == C, prec f16x3;
- * d->tile: -1 heuristic, 6/7/9/10/11 = 128 x {128,64,96,192,256}, 12/13/14 = 256 x {256,192,128}, 15 = 256 x 128 with a
- * loader wave and a three-stage ring (same results).  The result goes to y
+ * d->tile: -1 heuristic, 6/7/9/10/11 = 128 x {128,64,96,192,256}, 12/13/14 = 256 x {256,192,128}.  The result goes to y
  * (fp32 rows, ldy) or, when y_planes != NULL, to output planes (for the next GEMM).  mspi_split_planes_fwd converts fp32 rows. */
 int mspi_layernorm_sp_fwd(const float* x, int64_t ldx, int64_t sample_stride_x, void* planes, int64_t ldo, int64_t plane,
                           const float* gamma, const float* beta, float eps, int32_t N, int32_t R, int32_t C, int32_t act,

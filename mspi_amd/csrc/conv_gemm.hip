@@ -398,7 +398,6 @@ namespace mspi {
 int launch_conv_ad(ConvArgs& a, long Ml, int force_bn, int* cfg, hipStream_t s);
 int launch_conv_ad8(ConvArgs& a, long Ml, int bn, int* cfg, hipStream_t s);
 int launch_conv_sp(ConvArgs& a, long Ml, int bn, int rows, int* cfg, hipStream_t s);
-int launch_conv_ws(ConvArgs& a, long Ml, int* cfg, hipStream_t s);   // conv_gemm_ws.hip
 }
 
 static thread_local int g_last_cfg = 0;
@@ -675,8 +674,7 @@ extern "C" int mspi_gemm_sp_fwd(const MspiConvDesc* d, const void* x_planes, int
     default: bn = d->Cout <= 64 ? 64 : (d->Cout % 192 == 0 ? 192 : 128); break;
   }
   int cfg = 0;
-  // 15: 256 x 128 with a loader wave and a three-stage ring (conv_gemm_ws.hip)
-  const int rc = d->tile == 15 ? launch_conv_ws(a, Ml, &cfg, (hipStream_t)stream) : launch_conv_sp(a, Ml, bn, rows, &cfg, (hipStream_t)stream);
+  const int rc = launch_conv_sp(a, Ml, bn, rows, &cfg, (hipStream_t)stream);
   MSPI_REQUIRE(rc == 0, "mspi_gemm_sp_fwd: tile %d could not be launched", d->tile);
   g_last_cfg = cfg;
   return check_launch("mspi_gemm_sp_fwd");

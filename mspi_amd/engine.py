@@ -564,8 +564,8 @@ def _out_extent(T, H, W, k, s, p):
     return ((T + 2 * p[0] - k[0]) // s[0] + 1, (H + 2 * p[1] - k[1]) // s[1] + 1, (W + 2 * p[2] - k[2]) // s[2] + 1)
 
 
-# mspi_gemm_sp_fwd: 128 x {128,64,96,192,256}, 256 x {256,192,128}; 15 = 256 x 128, loader wave + 8 MFMA waves (conv_gemm_ws.hip)
-SP_TILES = (6, 7, 9, 10, 11, 12, 13, 14, 15)
+# mspi_gemm_sp_fwd: 128 x {128,64,96,192,256}, 256 x {256,192,128}
+SP_TILES = (6, 7, 9, 10, 11, 12, 13, 14)
 
 
 def _conv_sp(x, pk, out, res, act, tile, sp_out):
@@ -614,7 +614,7 @@ def _conv_sp(x, pk, out, res, act, tile, sp_out):
     elif AUTOTUNE["on"] and not torch.cuda.is_current_stream_capturing():
         choice = AUTOTUNE["cache"].get(key)
         if choice is None:
-            choice = _tune_conv(launch, key, [t for t in SP_TILES if t < 12 or M >= 4096])     # 12..15: 256-row tiles
+            choice = _tune_conv(launch, key, [t for t in SP_TILES if t < 12 or M >= 4096])
     elif key in AUTOTUNE["cache"]:
         choice = AUTOTUNE["cache"][key]
     with _Timed("conv_gemm", 2.0 * M * pk.cin * pk.cout, 4.0 * (M * pk.cin + M * pk.cout * (2 if res is not None else 1) + pk.cout * pk.cin),

@@ -52,7 +52,7 @@ for M, K, N in SHAPES:
     d.To, d.Ho, d.Wo, d.Cout = 1, 1, M, N
     d.ldy, d.ldw, d.ldr, d.act, d.prec, d.w_scale = N, pk.ldw, 0, E.ACT_GELU, pk.prec, pk.w_scale
     res = {}
-    for t in [6, 7, 9, 10, 11, 12, 13, 14, 15]:
+    for t in [6, 7, 9, 10, 11, 12, 13, 14]:
         d.tile = t
         def run():
             _lib.check(lib.mspi_gemm_sp_fwd(C.byref(d), planes.data_ptr(), K, M * K, pk.w.data_ptr(), pk.bias.data_ptr(), None,
