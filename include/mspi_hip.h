@@ -346,6 +346,29 @@ int mspi_rowgemm_supported(int32_t K, int32_t N);
 int mspi_rowgemm_fwd(const MspiRowGemmDesc* d, const void* x, const void* w_packed, const void* bias, const void* res,
                      const void* gate, void* y, mspi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * X3D block seam, one launch for the end of block i and the start of block i+1 of a stage (csrc/mlp_fused.hip):
+ *   y[M, Cx] = relu( u'[M, D] . Wc^T + bc + res ),   u' = u, or swish(u * gate[row / rows_per_sample]) when gate != NULL
+ *   t[M, D]  = relu( y . Wa^T + ba )
+ * Replaces: X3DTransform.c + c_bn, the residual add and ReLU of ResBlock.forward (SlowFast/resnet_helper.py:339-351,
+ * :607-616), followed by the next block's X3DTransform.a + a_bn + a_relu (:296-307); the SE scale (:333) and Swish
+ * (:339) of block i are the gate prologue, as in mspi_rowgemm_fwd.  Results are those of the two mspi_rowgemm_fwd
+ * calls it stands for, up to fp32 summation order.
+ * D: stored columns of u and t (the stage's inner width, <= 224), Cx: stored columns of res and y (<= 256); multiples of 4.
+ * w_packed: mspi_x3d_ca_packed_bytes(D, Cx) bytes = mspi_mlp_fwd's packing with C = D padded to 128 or 224,
+ * hidden = Cx padded to 32, W1s = wc_scale * Wc [Cx, D], W2s = wa_scale * Wa [D, Cx], zero padding (engine.pack_x3d_ca). */
+typedef struct {
+  int64_t M;
+  int32_t D, Cx;
+  int64_t ldu, ldr, ldy, ldt, ldg;   /* row strides in floats */
+  int32_t rows_per_sample;
+  float wc_scale, wa_scale;
+} MspiX3dCaDesc;
+size_t mspi_x3d_ca_packed_bytes(int32_t D, int32_t Cx);
+int mspi_x3d_ca_supported(int32_t D, int32_t Cx);
+int mspi_x3d_ca_fwd(const MspiX3dCaDesc* d, const void* u, const void* gate, const void* w_packed, const void* bc,
+                    const void* ba, const void* res, void* y, void* t, mspi_stream_t stream);
+
 /* Saliency metrics (utils/compute_saliency_metrics.py:9-108; the terms of utils/loss.py:26-49): per sample n,
  * out[n] = { KL(gt || pred), CC(pred, gt), SIM(pred, gt), NSS(pred, fix) } over the L = H*W values of each map.
  * pred is the predicted map (pred_is_log: the model's log-probability map, exponentiated on the fly), gt the

@@ -84,6 +84,14 @@ class RowGemmDesc(C.Structure):
     ]
 
 
+class X3dCaDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int64), ("D", C.c_int32), ("Cx", C.c_int32),
+        ("ldu", C.c_int64), ("ldr", C.c_int64), ("ldy", C.c_int64), ("ldt", C.c_int64), ("ldg", C.c_int64),
+        ("rows_per_sample", C.c_int32), ("wc_scale", C.c_float), ("wa_scale", C.c_float),
+    ]
+
+
 class X3dAbDesc(C.Structure):
     _fields_ = [
         ("N", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
@@ -143,6 +151,9 @@ _SIGNATURES = {
     "mspi_rowgemm_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "mspi_rowgemm_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "mspi_rowgemm_fwd": (C.c_int, [C.POINTER(RowGemmDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "mspi_x3d_ca_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "mspi_x3d_ca_supported": (C.c_int, [C.c_int32, C.c_int32]),
+    "mspi_x3d_ca_fwd": (C.c_int, [C.POINTER(X3dCaDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mspi_x3d_ab_supported": (C.c_int, [C.POINTER(X3dAbDesc)]),
     "mspi_x3d_ab_pool_rows": (C.c_int, [C.POINTER(X3dAbDesc)]),
     "mspi_x3d_ab_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),

@@ -136,6 +136,8 @@ class Swish(nn.Module):
 # MSPI_X3D_FUSE = 0 (never) | 1 (every stride-1 block the kernel covers) | auto (default)
 FUSE_AB = os.environ.get("MSPI_X3D_FUSE", "auto")
 FUSE_MIN_W = 56
+# Block seam (`c` of block i + `a` of block i+1 in one launch, csrc/mlp_fused.hip): MSPI_X3D_SEAM = 0 switches it off (A/B)
+SEAM = os.environ.get("MSPI_X3D_SEAM", "1")
 
 
 class X3DTransform(HipModule):
@@ -179,24 +181,29 @@ class X3DTransform(HipModule):
                         E._pad_vec(self.se.fc2.bias, cs_mid))
         return pk
 
-    def run(self, x, res, out=None):
-        """res: skip tensor added before the final ReLU."""
+    def uses_ab(self, x):
+        """Whether run(x) takes the fused a + b kernel (which computes `a` itself: no seam into this block)."""
         pk = self.pk
+        return pk["ab"] is not None and (FUSE_AB == "1" or x.W >= FUSE_MIN_W) and E.x3d_ab_supported(x, pk["ab"])
+
+    def run(self, x, res, out=None, t=None, seam=None):
+        """res: skip tensor added before the final ReLU.
+        t: relu(a_bn(a(x))), when the previous block's seam launch already produced it.
+        seam: PackedX3dCa of this block's `c` and the next block's `a` -> returns (y, t of the next block)."""
+        pk = self.pk
+        se = "se" in pk
         # the fused kernel is built from `a`'s f16x3 planes: it follows that pack's first-sight range check
-        if pk["ab"] is not None and (FUSE_AB == "1" or x.W >= FUSE_MIN_W) and E.x3d_ab_supported(x, pk["ab"]) \
-                and E.range_check_input(pk["a"], x):
-            if "se" in pk:
-                u, part = E.x3d_ab(x, pk["ab"], pool=True)
-                gate = E.se_gate(part, 1.0 / (u.T * u.H * u.W), *pk["se"])
-                return E.conv(u, pk["c"], res=res, gate=gate, out=out)
-            return E.conv(E.x3d_ab(x, pk["ab"]), pk["c"], res=res, out=out)
-        t = E.conv(x, pk["a"])
-        if "se" in pk:
-            u, part = E.dwconv(t, pk["b"], pool=True)
+        if t is None and self.uses_ab(x) and E.range_check_input(pk["a"], x):
+            u = E.x3d_ab(x, pk["ab"], pool=se)
+        else:
+            u = E.dwconv(E.conv(x, pk["a"]) if t is None else t, pk["b"], pool=se)
+        gate = None
+        if se:
+            u, part = u
             gate = E.se_gate(part, 1.0 / (u.T * u.H * u.W), *pk["se"])
-            return E.conv(u, pk["c"], res=res, gate=gate, out=out)
-        u = E.dwconv(t, pk["b"])
-        return E.conv(u, pk["c"], res=res, out=out)
+        if seam is not None:
+            return E.x3d_ca(u, seam, res, gate=gate)
+        return E.conv(u, pk["c"], res=res, gate=gate, out=out)
 
 
 class BottleneckTransform(HipModule):
@@ -245,9 +252,9 @@ class ResBlock(HipModule):
                                cin_stored=E.rup4(c.in_channels))
         return None
 
-    def run(self, x, out=None):
+    def run(self, x, out=None, **seam):
         skip = E.conv(x, self.pk) if self.pk is not None else x
-        return self.branch2.run(x, skip, out=out)
+        return self.branch2.run(x, skip, out=out, **seam)
 
 
 class ResStage(HipModule):
@@ -271,6 +278,20 @@ class ResStage(HipModule):
     def blocks(self, p):
         return [getattr(self, "pathway{}_res{}".format(p, i)) for i in range(self.num_blocks[p])]
 
+    def _pack(self):
+        """Per pathway, per block i: the seam pack of block i's `c` and block i+1's `a` (X3D stride-1 neighbours), or None."""
+        seams = []
+        for p in range(self.num_pathways):
+            bl = self.blocks(p)
+            row = [None] * len(bl)
+            for i in range(len(bl) - 1):
+                a, b = bl[i].branch2, bl[i + 1].branch2
+                if SEAM != "0" and isinstance(a, X3DTransform) and isinstance(b, X3DTransform) and not hasattr(bl[i + 1], "branch1") \
+                        and tuple(b.a.stride) == (1, 1, 1):
+                    row[i] = E.pack_x3d_ca(a.pk["c"], b.pk["a"])
+            seams.append(row)
+        return seams
+
     def run(self, xs, outs=None, pathways=None):
         """outs[p]: where pathway p's last block writes (a channel slice of a concat buffer).
         pathways: subset to compute."""
@@ -281,7 +302,23 @@ class ResStage(HipModule):
                 continue
             x = xs[p]
             blocks = self.blocks(p)
+            seams = self.pk[p]
+            t = None
             for bi, b in enumerate(blocks):
-                x = b.run(x, out=outs[p] if (outs is not None and bi == len(blocks) - 1) else None)
+                kw = {}
+                if t is not None:
+                    kw["t"] = t
+                    t = None
+                sm = seams[bi]
+                # a seam launch stands for two packed layers: it is used once both have passed their first-sight range check
+                # (the tuning forward runs them as separate launches) and while both are still on the f16x3 path
+                nxt_ab = sm is not None and blocks[bi + 1].branch2.pk["ab"] is not None and \
+                    (FUSE_AB == "1" or x.W // b.branch2.b.stride[2] >= FUSE_MIN_W)      # the next block computes its own `a`
+                if sm is not None and not nxt_ab:
+                    pc, pa = b.branch2.pk["c"], blocks[bi + 1].branch2.pk["a"]
+                    if pc.prec == pa.prec == E.PREC_F16X3 and not (E._tuning() and not (pc.checked and pa.checked)):
+                        x, t = b.run(x, seam=sm, **kw)
+                        continue
+                x = b.run(x, out=outs[p] if (outs is not None and bi == len(blocks) - 1) else None, **kw)
             out.append(x)
         return out

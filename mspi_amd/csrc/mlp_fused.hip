@@ -480,3 +480,228 @@ extern "C" int mspi_rowgemm_fwd(const MspiRowGemmDesc* d, const void* x, const v
   MSPI_REQUIRE(rc == 0, "mspi_rowgemm_fwd: could not reserve %zu bytes of LDS", lds);
   return check_launch("mspi_rowgemm_fwd");
 }
+
+// =====================================================================================================
+// X3D block seam:  y = relu( Wc . g(u) + bc + x )          (this block's `c` conv, residual, ReLU  -> the block output)
+//                  t = relu( Wa'. y + ba' )                (the NEXT block's `a` conv)
+// with g(u) = swish(u * gate[sample]) for squeeze-excite blocks, identity otherwise.
+//
+// Stages 3-4 of X3D-L are 9 / 24 stride-1 blocks of three small layers each; as separate launches `c` (21-26 us) and the
+// following `a` (17 us) are each one exposed load -> compute -> store round trip for a few MB (profiles/r03_x3d_stage_kernel.txt).
+// This is the fused MLP above with the roles changed: the wave keeps its 32 rows of u as MFMA B fragments, walks the block
+// width (y's columns) in chunks of 32 -- phase 1 computes the chunk of y^T, its epilogue adds bias + residual, applies the
+// ReLU, STORES the chunk of y and keeps it (split) as phase 2's B operand -- and accumulates all of t^T across the chunks.
+// Packing = mspi_mlp's with C = the dw width padded to 128 / 224 and hidden = the block width padded to 32
+// (engine.pack_x3d_ca); padded channels are zero weights / zero bias and are never loaded or stored.
+namespace mspi {
+
+struct CaArgs {
+  const float* u; const float* gate; const unsigned char* wp; const float* b1; const float* b2; const float* res;
+  float* y; float* t;
+  long M, ldu, ldg, ldr, ldy, ldt;
+  int D, Cx;          // stored columns of u / t and of x / y (multiples of 4)
+  int nch;            // ceil(Cx / 32)
+  int rows_per_sample;
+  float inv_s1, inv_s2;
+  int* status;
+};
+
+template <int C, bool GATE>
+__global__ __launch_bounds__(256, 1) void x3d_ca_kernel(const CaArgs p) {
+  constexpr int NS = 2;
+  constexpr int KS = C / 16, CT = C / 32;
+  constexpr int W1B = KS * 2048, W2B = 2 * CT * 2048, SB = W1B + W2B;
+  constexpr int DPW = SB / 4096;
+  static_assert(C % 32 == 0 && SB % 4096 == 0, "C: multiple of 32");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SB + 1024];   // the ring, then bc (<= 256 floats)
+  float* b1s = reinterpret_cast<float*>(smem + NS * SB);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const long row = (long)blockIdx.x * 128 + wave * 32 + li;
+  const bool rok = row < p.M;
+  const long rr = rok ? row : p.M - 1;
+
+  auto issue_stage = [&](int j) {
+    const unsigned char* src = p.wp + (long)j * SB + (wave * DPW) * 1024 + lane * 16;
+    unsigned char* dst = smem + (j % NS) * SB + (wave * DPW) * 1024;
+#pragma unroll
+    for (int d = 0; d < DPW; ++d)
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src + d * 1024), (lds_void*)(dst + d * 1024), 16, 0, 0);
+  };
+  for (int j = 0; j < NS - 1 && j < p.nch; ++j) issue_stage(j);
+
+  float xr[KS][8];
+  const float* xp = p.u + rr * p.ldu + 8 * lh;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int k = 16 * ks + 8 * lh;
+    const bool k0 = k < p.D, k1 = k + 4 < p.D;
+    const float4 a = *reinterpret_cast<const float4*>(xp + (k0 ? 16 * ks : -8 * lh));
+    const float4 b = *reinterpret_cast<const float4*>(xp + (k1 ? 16 * ks + 4 : -8 * lh));
+    xr[ks][0] = k0 ? a.x : 0.f; xr[ks][1] = k0 ? a.y : 0.f; xr[ks][2] = k0 ? a.z : 0.f; xr[ks][3] = k0 ? a.w : 0.f;
+    xr[ks][4] = k1 ? b.x : 0.f; xr[ks][5] = k1 ? b.y : 0.f; xr[ks][6] = k1 ? b.z : 0.f; xr[ks][7] = k1 ? b.w : 0.f;
+  }
+  if (GATE) {
+    const float* gp = p.gate + (rr / p.rows_per_sample) * p.ldg + 8 * lh;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 16 * ks + 8 * lh;
+      const bool k0 = k < p.D, k1 = k + 4 < p.D;
+      const float4 a = *reinterpret_cast<const float4*>(gp + (k0 ? 16 * ks : -8 * lh));
+      const float4 b = *reinterpret_cast<const float4*>(gp + (k1 ? 16 * ks + 4 : -8 * lh));
+      const float g8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = xr[ks][e] * g8[e];
+        xr[ks][e] = v / (1.f + __expf(-v));     // Swish (zero stays zero: masked k contribute nothing)
+      }
+    }
+  }
+  for (int i = tid; i < p.nch * 32; i += 256) b1s[i] = i < p.Cx ? p.b1[i] : 0.f;
+  v8h xh[KS], xl[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      _Float16 h, l;
+      split_f16(xr[ks][e], h, l);
+      xh[ks][e] = h; xl[ks][e] = l;
+    }
+
+  v16f o[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[ct][i] = 0.f;
+
+  bool bad = false;
+  for (int j = 0; j < p.nch; ++j) {
+    // stage j has landed (vmcnt(0): also this wave's y stores of chunk j-1); the barrier also says every wave is done
+    // reading stage j-1, whose slot the next DMA overwrites
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (j + NS - 1 < p.nch) issue_stage(j + NS - 1);
+    // residual chunk: in flight under phase 1
+    float4 rv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = j * 32 + q * 8 + 4 * lh;
+      rv[q] = c < p.Cx ? *reinterpret_cast<const float4*>(p.res + rr * p.ldr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    const unsigned char* st = smem + (j % NS) * SB + lane * 16;
+    v16f h;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) h[i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const v8h wh = *reinterpret_cast<const v8h*>(st + (ks * 2 + 0) * 1024);
+      const v8h wl = *reinterpret_cast<const v8h*>(st + (ks * 2 + 1) * 1024);
+      if (!kSingleProduct) {
+        h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[ks], h, 0, 0, 0);
+        h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[ks], h, 0, 0, 0);
+      }
+      h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[ks], h, 0, 0, 0);
+    }
+    // ---- y chunk: acc index i <-> column j*32 + (i/4)*8 + 4*lh + i%4;  bias + residual + ReLU, store, split
+    v8h hh[2], hl[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = j * 32 + q * 8 + 4 * lh;
+      const float4 b = *reinterpret_cast<const float4*>(b1s + c);
+      float4 v;
+      v.x = fmaf(h[q * 4 + 0], p.inv_s1, b.x) + rv[q].x;
+      v.y = fmaf(h[q * 4 + 1], p.inv_s1, b.y) + rv[q].y;
+      v.z = fmaf(h[q * 4 + 2], p.inv_s1, b.z) + rv[q].z;
+      v.w = fmaf(h[q * 4 + 3], p.inv_s1, b.w) + rv[q].w;
+      bad |= rok && (nonfinite(v.x) | nonfinite(v.y) | nonfinite(v.z) | nonfinite(v.w));
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      if (rok && c < p.Cx) *reinterpret_cast<float4*>(p.y + row * p.ldy + c) = v;
+      const float v4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        _Float16 f, l;
+        split_f16(v4[r], f, l);
+        hh[q >> 1][(q & 1) * 4 + r] = f;
+        hl[q >> 1][(q & 1) * 4 + r] = l;
+      }
+    }
+    // ---- phase 2: t^T += Wa'[:, chunk] . y chunk
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const v8h wh = *reinterpret_cast<const v8h*>(st + W1B + ((s * CT + ct) * 2 + 0) * 1024);
+        const v8h wl = *reinterpret_cast<const v8h*>(st + W1B + ((s * CT + ct) * 2 + 1) * 1024);
+        if (!kSingleProduct) {
+          o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hh[s], o[ct], 0, 0, 0);
+          o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hl[s], o[ct], 0, 0, 0);
+        }
+        o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hh[s], o[ct], 0, 0, 0);
+      }
+  }
+
+  // ---- t: lane (li, lh) holds, for row li, channels ct*32 + q*8 + 4*lh + 0..3
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = ct * 32 + q * 8 + 4 * lh;
+      if (c < p.D) {
+        const float4 b = *reinterpret_cast<const float4*>(p.b2 + c);
+        float4 v;
+        v.x = fmaf(o[ct][q * 4 + 0], p.inv_s2, b.x);
+        v.y = fmaf(o[ct][q * 4 + 1], p.inv_s2, b.y);
+        v.z = fmaf(o[ct][q * 4 + 2], p.inv_s2, b.z);
+        v.w = fmaf(o[ct][q * 4 + 3], p.inv_s2, b.w);
+        bad |= rok && (nonfinite(v.x) | nonfinite(v.y) | nonfinite(v.z) | nonfinite(v.w));
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        if (rok) *reinterpret_cast<float4*>(p.t + row * p.ldt + c) = v;
+      }
+    }
+  report_nonfinite(p.status, bad);
+}
+
+}  // namespace mspi
+
+static int x3d_ca_c(int D) { return D <= 128 ? 128 : D <= 224 ? 224 : 0; }
+
+extern "C" int mspi_x3d_ca_supported(int32_t D, int32_t Cx) {
+  return x3d_ca_c(D) != 0 && D >= 4 && D % 4 == 0 && Cx >= 4 && Cx % 4 == 0 && Cx <= 256;
+}
+
+extern "C" size_t mspi_x3d_ca_packed_bytes(int32_t D, int32_t Cx) {
+  const int c = x3d_ca_c(D);
+  return c ? mspi_mlp_packed_bytes(c, (Cx + 31) / 32 * 32) : 0;
+}
+
+extern "C" int mspi_x3d_ca_fwd(const MspiX3dCaDesc* d, const void* u, const void* gate, const void* w_packed, const void* bc,
+                               const void* ba, const void* res, void* y, void* t, void* stream) {
+  MSPI_REQUIRE(d && u && w_packed && bc && ba && res && y && t, "mspi_x3d_ca_fwd: null argument");
+  MSPI_REQUIRE(mspi_x3d_ca_supported(d->D, d->Cx), "mspi_x3d_ca_fwd: D = %d / Cx = %d outside the kernel's range", d->D, d->Cx);
+  MSPI_REQUIRE(d->M >= 1 && d->M < (1L << 31), "mspi_x3d_ca_fwd: M = %ld", (long)d->M);
+  MSPI_REQUIRE(d->ldu >= d->D && d->ldt >= d->D && d->ldr >= d->Cx && d->ldy >= d->Cx &&
+               d->ldu % 4 == 0 && d->ldt % 4 == 0 && d->ldr % 4 == 0 && d->ldy % 4 == 0,
+               "mspi_x3d_ca_fwd: row strides must cover the row and be multiples of 4 floats");
+  MSPI_REQUIRE(!gate || (d->rows_per_sample > 0 && d->ldg >= d->D && d->ldg % 4 == 0), "mspi_x3d_ca_fwd: gate needs rows_per_sample and ldg");
+  MSPI_REQUIRE(d->wc_scale > 0.f && d->wa_scale > 0.f, "mspi_x3d_ca_fwd: weight scales must be positive");
+  CaArgs a;
+  a.u = (const float*)u; a.gate = (const float*)gate; a.wp = (const unsigned char*)w_packed; a.b1 = (const float*)bc;
+  a.b2 = (const float*)ba; a.res = (const float*)res; a.y = (float*)y; a.t = (float*)t;
+  a.M = d->M; a.ldu = d->ldu; a.ldg = d->ldg; a.ldr = d->ldr; a.ldy = d->ldy; a.ldt = d->ldt;
+  a.D = d->D; a.Cx = d->Cx; a.nch = (d->Cx + 31) / 32; a.rows_per_sample = d->rows_per_sample;
+  a.inv_s1 = 1.0f / d->wc_scale; a.inv_s2 = 1.0f / d->wa_scale;
+  a.status = g_status_word;
+  const dim3 grid((unsigned)((a.M + 127) / 128));
+  hipStream_t s = (hipStream_t)stream;
+  if (x3d_ca_c(d->D) == 128) {
+    if (gate) hipLaunchKernelGGL((x3d_ca_kernel<128, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((x3d_ca_kernel<128, false>), grid, dim3(256), 0, s, a);
+  } else {
+    if (gate) hipLaunchKernelGGL((x3d_ca_kernel<224, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((x3d_ca_kernel<224, false>), grid, dim3(256), 0, s, a);
+  }
+  return check_launch("mspi_x3d_ca_fwd");
+}

@@ -553,6 +553,65 @@ def x3d_ab(x, pk, pool=False):
     return (out, part) if pool else out
 
 
+class PackedX3dCa:
+    __slots__ = ("w", "bc", "ba", "d", "cx", "cx_s", "d_s", "wc_scale", "wa_scale")
+
+
+def x3d_ca_supported(d_s, cx_s):
+    """Mirror of mspi_x3d_ca_supported."""
+    return 4 <= d_s <= 224 and d_s % 4 == 0 and 4 <= cx_s <= 256 and cx_s % 4 == 0
+
+
+def pack_x3d_ca(pc, pa):
+    """Operands of the fused X3D block seam (mspi_x3d_ca_fwd): this block's `c` conv `pc` and the next block's `a` conv `pa`
+    (both PackedConv, 1x1x1, f16x3, ReLU); None when the pair is outside the kernel's range."""
+    ok = all(q.prec == PREC_F16X3 and q.k == (1, 1, 1) and q.stride == (1, 1, 1) and q.pad == (0, 0, 0) and q.act == ACT_RELU
+             and q.bias is not None for q in (pc, pa))
+    if not ok or pc.cout_s != pa.cin_s or pc.cin_s != pa.cout_s or not x3d_ca_supported(pc.cin_s, pc.cout_s):
+        return None
+    d_s, cx_s = pc.cin_s, pc.cout_s
+    c = 128 if d_s <= 128 else 224
+    hid = (cx_s + 31) // 32 * 32
+    nch, ks, ct = hid // 32, c // 16, c // 32
+    w1 = torch.zeros(hid, c, dtype=torch.float32)
+    w1[:cx_s, :d_s] = (pc.w[0].float() + pc.w[1].float()).cpu()[:, :d_s]      # hi + lo = the scaled fp32 weight's 22 bits
+    w2 = torch.zeros(c, hid, dtype=torch.float32)
+    w2[:d_s, :cx_s] = (pa.w[0].float() + pa.w[1].float()).cpu()[:, :cx_s]
+
+    def planes(ws):
+        hi = ws.to(torch.float16)
+        return hi, (ws - hi.float()).to(torch.float16)
+
+    parts1 = [pl.view(nch, 32, ks, 2, 8).permute(0, 2, 3, 1, 4).reshape(nch, ks, 64, 8) for pl in planes(w1)]
+    parts2 = [pl.view(ct, 32, nch, 2, 2, 2, 4).permute(2, 3, 0, 5, 1, 4, 6).reshape(nch, 2, ct, 64, 8) for pl in planes(w2)]
+    p = PackedX3dCa()
+    p.w = torch.cat([torch.stack(parts1, 2).reshape(nch, -1), torch.stack(parts2, 3).reshape(nch, -1)], 1).contiguous().to(pc.w.device)
+    p.bc, p.ba = pc.bias, pa.bias
+    p.d, p.d_s, p.cx, p.cx_s, p.wc_scale, p.wa_scale = pc.cin, d_s, pc.cout, cx_s, pc.w_scale, pa.w_scale
+    return p
+
+
+def x3d_ca(u, pk, res, gate=None):
+    """(y, t) = (relu(c(u') + res), relu(a_next(y))) in one launch (csrc/mlp_fused.hip); u' = swish(u * gate) with a gate."""
+    lib = _lib.load()
+    _need_gpu(u.buf)
+    if not (u.dense and res.dense) or u.Cs != pk.d_s or res.Cs != pk.cx_s or res.M != u.M:
+        raise MspiError("x3d_ca: u %s / res %s do not match the pack (%d, %d)" % ((u.M, u.Cs), (res.M, res.Cs), pk.d_s, pk.cx_s))
+    if pk.w.device != u.buf.device:
+        raise MspiError("x3d_ca: packed weights live on %s, the input on %s" % (pk.w.device, u.buf.device))
+    y = alloc(u.N, u.T, u.H, u.W, pk.cx, u.buf.device)
+    t = alloc(u.N, u.T, u.H, u.W, pk.d, u.buf.device)
+    d = _lib.X3dCaDesc()
+    d.M, d.D, d.Cx = u.M, pk.d_s, pk.cx_s
+    d.ldu, d.ldr, d.ldy, d.ldt, d.ldg = u.ld, res.ld, y.ld, t.ld, pk.d_s
+    d.rows_per_sample, d.wc_scale, d.wa_scale = u.T * u.H * u.W, pk.wc_scale, pk.wa_scale
+    with _Timed("x3d_ca", 4.0 * u.M * pk.d * pk.cx, 4.0 * u.M * (2 * pk.d + 2 * pk.cx),
+                "M=%d D=%d Cx=%d%s" % (u.M, pk.d, pk.cx, " +gate" if gate is not None else "")):
+        check(lib.mspi_x3d_ca_fwd(C.byref(d), u.ptr, gate.data_ptr() if gate is not None else None, pk.w.data_ptr(),
+                                  pk.bc.data_ptr(), pk.ba.data_ptr(), res.ptr, y.ptr, t.ptr, _stream()), "mspi_x3d_ca_fwd")
+    return y, t
+
+
 def _pad_vec(v, n):
     out = torch.zeros(n, dtype=torch.float32, device=v.device)
     out[: v.numel()] = v.detach().float().view(-1)

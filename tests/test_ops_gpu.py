@@ -624,6 +624,54 @@ def test_x3d_ab_fused(dev, case, se):
     _close(u.as_ncdhw(Cmid), v.as_ncdhw(Cmid).cpu(), 2e-5, "fused vs unfused")
 
 
+@pytest.mark.parametrize("case", [(216, 96, 1000), (108, 48, 777), (54, 24, 420), (216, 96, 128 * 6)])
+@pytest.mark.parametrize("se", [False, True])
+def test_x3d_ca_seam(dev, case, se):
+    """mspi_x3d_ca_fwd: y = relu(c(u') + res), t = relu(a_next(y)) in one launch (u' = swish(u * gate) for SE blocks) against
+    torch fp64 (X3DTransform.c + ResBlock add/ReLU + next X3DTransform.a, SlowFast/resnet_helper.py:296-351, :607-616) and
+    against the two thin-GEMM launches it stands for; widths that are not multiples of 32, ragged M, pad columns."""
+    from mspi_amd import engine as E
+    from mspi_amd.module import to_cl
+    if E.DEFAULT_PREC != E.PREC_F16X3:
+        pytest.skip("the seam kernel is an f16x3 kernel")
+    D, Cx, M = case
+    g = torch.Generator().manual_seed(D + Cx + M)
+    N, rows = 3, (M + 2) // 3
+    u = torch.randn(N, D, 1, rows, 1, generator=g)
+    r = torch.randn(N, Cx, 1, rows, 1, generator=g)
+    wc = torch.randn(Cx, D, 1, 1, 1, generator=g) / math.sqrt(D)
+    bc = torch.randn(Cx, generator=g) * 0.3
+    wa = torch.randn(D, Cx, 1, 1, 1, generator=g) / math.sqrt(Cx)
+    ba = torch.randn(D, generator=g) * 0.3
+    gt = torch.rand(N, D, generator=g) * 2 if se else None
+    uin = u.double()
+    if se:
+        uin = F.silu(uin * gt.double()[:, :, None, None, None])
+    y_ref = F.relu(F.conv3d(uin, wc.double(), bc.double()) + r.double())
+    t_ref = F.relu(F.conv3d(y_ref, wa.double(), ba.double()))
+    uc, rc = to_cl(u.to(dev)), to_cl(r.to(dev))
+    pc = E.pack_conv(wc, bc, act=E.ACT_RELU, cin_stored=uc.Cs, device=dev)
+    pa = E.pack_conv(wa, ba, act=E.ACT_RELU, cin_stored=rc.Cs, device=dev)
+    pk = E.pack_x3d_ca(pc, pa)
+    assert pk is not None
+    assert pk.w.numel() * 2 == E._lib.load().mspi_x3d_ca_packed_bytes(uc.Cs, rc.Cs)
+    gd = None
+    if se:
+        gd = torch.zeros(N, uc.Cs, device=dev)
+        gd[:, :D] = gt.to(dev)
+    y, t = E.x3d_ca(uc, pk, rc, gate=gd)
+    _close(y.as_ncdhw(Cx), y_ref.float(), 2e-5, "seam: y")
+    _close(t.as_ncdhw(D), t_ref.float(), 2e-5, "seam: t")
+    y2 = E.conv(uc, pc, res=rc, gate=gd, tile=E.THIN)
+    t2 = E.conv(y2, pa, tile=E.THIN)
+    _close(y.as_ncdhw(Cx), y2.as_ncdhw(Cx).cpu(), 2e-6, "seam vs thin GEMM: y")
+    if y.Cs > Cx:   # pad channels stay exact zeros
+        assert (y.as_rows()[:, Cx:] == 0).all()
+    _close(t.as_ncdhw(D), t2.as_ncdhw(D).cpu(), 2e-5, "seam vs two launches")
+    y3, t3 = E.x3d_ca(uc, pk, rc, gate=gd)
+    assert torch.equal(y.buf, y3.buf) and torch.equal(t.buf, t3.buf)
+
+
 def _range_case(dev, scale_rows, M=512, K=192, N=96, seed=5):
     from mspi_amd import engine as E
     from mspi_amd.module import to_cl

@@ -40,7 +40,7 @@ for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
     print("  %-28s calls %4d  %7.3f ms/fwd (%4.1f%%)  avg %6.1f us" % (k, d["calls"] // 3, d["ms"] / 3, 100 * d["ms"] / tot, 1e3 * d["ms"] / d["calls"]))
 agg = {}
 for name, fl, by, e0, e1, det in prof.records:
-    if name.startswith("x3d_ab"):
+    if name.startswith("x3d_") or os.environ.get("X3D_PROBE_ALL"):
         a = agg.setdefault((name, det), [0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1)
 for (name, det), a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print("    %-12s x%-3d %7.1f us  %s" % (name, a[0] // 3, 1e3 * a[1] / a[0], det))
+    print("    %-28s x%-3d %7.1f us  %s" % (name, a[0] // 3, 1e3 * a[1] / a[0], det))
