@@ -35,6 +35,9 @@ struct AttnArgs {
   _Float16* kp;
   _Float16* vp;
   int Nkp;
+  // key split (gridDim.z > 1): slice z of the key tiles leaves its unnormalised O^T, running maximum and running sum here
+  float* part_o;       // [z][B*Hh][Nq][DV]
+  float* part_ml;      // [z][B*Hh][Nq][2]
 };
 
 // D = head dim of Q/K (the contraction of S), DV = head dim of V / O.  They differ for MViT, whose decomposed
@@ -210,7 +213,7 @@ __device__ __forceinline__ void split4(const float4 v, v4h& hi, v4h& lo) {
 #ifndef MSPI_ATT_PV_DROP
 #define MSPI_ATT_PV_DROP 0
 #endif
-constexpr float ATT_KSC = 16.f, ATT_VSC = 16.f;
+constexpr float ATT_KSC = 16.f, ATT_VSC = 16.f, ATT_PSC = 1024.f;
 
 // K and V of every (sequence, head) split ONCE into the f16 hi/lo planes the attention kernel stages: every query tile of
 // that head (196 workgroups at Nq = 25088) used to redo this split on its own copy -- ~200 VALU instructions per thread and
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
   // Power-of-two operand scales (exact; undone on the fp32 side).  The lo half of a split value is ~2^-12 of it, and
   // f16 loses precision below 2^-14 (subnormals; the matrix pipe may flush them): q*scale ~ 0.1 and p <= 1 would keep
   // only their hi halves.  Scaled, every operand of ordinary magnitude has a NORMAL lo half.
-  constexpr float QSC = 64.f, KSC = ATT_KSC, PSC = 1024.f, VSC = ATT_VSC;
+  constexpr float QSC = 64.f, KSC = ATT_KSC, PSC = ATT_PSC, VSC = ATT_VSC;
   // With prefetched planes (PL && PF) the K / V tiles are DOUBLE-buffered in LDS: tile t+1 is written (from the registers the
   // prefetch filled) behind tile t's MFMAs, so a key tile costs one barrier, not two, and no wave waits for staging.
   constexpr int TILE = 2 * 32 * KP + 2 * DV * VP;
@@ -371,15 +374,22 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
       }
     }
   };
+  // key split: workgroup z of gridDim.z walks key tiles [kbeg, kend) (the host makes every slice non-empty)
+  int kbeg = 0, kend = p.Nk;
+  if (PL && PF && gridDim.z > 1) {
+    const int ntile = (p.Nk + 31) >> 5, tps = (ntile + gridDim.z - 1) / gridDim.z;
+    kbeg = blockIdx.z * tps * 32;
+    kend = min(p.Nk, kbeg + tps * 32);
+  }
   if (PL && PF) {
-    prefetch(0);
+    prefetch(kbeg);
     stage_write(smem);
-    if (32 < p.Nk) prefetch(32);
+    if (kbeg + 32 < kend) prefetch(kbeg + 32);
     __syncthreads();
   }
 
   int tsel = 0;
-  for (int k0 = 0; k0 < p.Nk; k0 += 32, tsel ^= 1) {
+  for (int k0 = kbeg; k0 < kend; k0 += 32, tsel ^= 1) {
     if (PL && PF) set_buf(tsel);
     if (!(PL && PF)) __syncthreads();  // previous tile fully consumed
     if (PL && !PF) prefetch(k0);
@@ -506,14 +516,27 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s2], acc[t], 0, 0, 0);
       }
     if (PL && PF) {
-      if (k0 + 32 < p.Nk) {
+      if (k0 + 32 < kend) {
         stage_write(smem + (tsel ^ 1) * TILE);                 // tile t+1 (fetched during this tile) into the other buffer
-        if (k0 + 64 < p.Nk) prefetch(k0 + 64);
+        if (k0 + 64 < kend) prefetch(k0 + 64);
       }
       __syncthreads();                                         // tile t consumed by every wave, tile t+1 visible
     }
   }
 
+  if (PL && PF && gridDim.z > 1) {
+    if (qok) {
+      const long pr = ((long)blockIdx.z * gridDim.y + blockIdx.y) * p.Nq + q;
+      if (lh == 0) *reinterpret_cast<float2*>(p.part_ml + pr * 2) = make_float2(m_run, l_run);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(p.part_o + pr * DV + t * 32 + 8 * g + 4 * lh) =
+              make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+    }
+    return;
+  }
   if (qok) {
     const float inv = 1.f / (l_run * (PSC * VSC));
     const long oo = (long)sample * p.o_sB + (long)h * p.o_sH + (long)qrow * p.o_sT;
@@ -531,6 +554,38 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
         *reinterpret_cast<float4*>(p.o + oo + dd) = o4;
       }
   }
+}
+
+// Key split, second pass: the slices' partial results are merged in fixed order z = 0, 1, .. (deterministic):
+//   M = max_z m_z,  w_z = 2^(m_z - M),  O = sum_z w_z O_z / (PSC VSC sum_z w_z l_z)  (+ res)
+template <int DV>
+__global__ __launch_bounds__(256) void attn_merge_kernel(const AttnArgs p, int nz) {
+  const long BH = (long)p.B * p.Hh;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= BH * p.Nq * (DV / 4)) return;
+  const int c4 = (int)(idx % (DV / 4));
+  const long row = idx / (DV / 4);          // bh * Nq + q
+  const int q = (int)(row % p.Nq);
+  const long bh = row / p.Nq;
+  float M = -INFINITY;
+  for (int z = 0; z < nz; ++z) M = fmaxf(M, p.part_ml[((long)z * BH * p.Nq + row) * 2]);
+  float L = 0.f;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < nz; ++z) {
+    const float2 ml = *reinterpret_cast<const float2*>(p.part_ml + ((long)z * BH * p.Nq + row) * 2);
+    const float w = __builtin_amdgcn_exp2f(ml.x - M);
+    L = fmaf(ml.y, w, L);
+    const float4 a = *reinterpret_cast<const float4*>(p.part_o + ((long)z * BH * p.Nq + row) * DV + c4 * 4);
+    o.x = fmaf(a.x, w, o.x); o.y = fmaf(a.y, w, o.y); o.z = fmaf(a.z, w, o.z); o.w = fmaf(a.w, w, o.w);
+  }
+  const float inv = 1.f / (L * (ATT_PSC * ATT_VSC));
+  o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+  const long oo = (bh / p.Hh) * p.o_sB + (bh % p.Hh) * p.o_sH + (long)q * p.o_sT + c4 * 4;
+  if (p.res) {
+    const float4 rr = *reinterpret_cast<const float4*>(p.res + oo);
+    o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+  }
+  *reinterpret_cast<float4*>(p.o + oo) = o;
 }
 
 // ------------------------------------------------------------------ MViTv2 decomposed relative positions
@@ -716,9 +771,34 @@ extern "C" int mspi_mvit_qk_augment(const MspiMvitAugDesc* d, const float* q, co
 
 static long attn_nkp(const MspiAttnDesc* d) { return ((long)d->Nk + 31) / 32 * 32; }
 
+// Key split for few-query shapes (MViTv2's last stage: 8 heads x 392 queries = 256 workgroups of up to 49 key tiles each, one
+// per CU at half occupancy): slices of the key tiles go to gridDim.z workgroups and a merge pass combines them.  Chosen so
+// that the grid reaches two workgroups per CU and no slice is shorter than 12 tiles (measured, batch 8: Nk = 1568 195.8 ->
+// 173.0 us, but Nk = 392 in two slices of 7 tiles 66.7 -> 71.6 us: the merge pass costs more than the second workgroup per
+// CU gains -- a CU retires one 128 x 32 tile step per ~3.3 us however many workgroups share it); 1 = no split.
+// MSPI_ATTN_KSPLIT=0: off.
+static int attn_ksplit(const MspiAttnDesc* d) {
+  static const char* env = getenv("MSPI_ATTN_KSPLIT");
+  if (env && env[0] == '0') return 1;
+  const long wgs = (((long)d->Nq + 127) / 128) * d->B * d->Hh;
+  const int ntile = (int)(attn_nkp(d) / 32);
+  int split = (int)(512 / (wgs > 0 ? wgs : 1));
+  if (split > ntile / 12) split = ntile / 12;
+  if (split > 8) split = 8;
+  while (split > 1 && (split - 1) * ((ntile + split - 1) / split) >= ntile) --split;    // every slice non-empty
+  return split < 2 ? 1 : split;
+}
+
+static size_t attn_planes_bytes(const MspiAttnDesc* d) {
+  const size_t b = (size_t)d->B * d->Hh * 2 * attn_nkp(d) * (size_t)(d->D + d->Dv) * sizeof(_Float16);
+  return (b + 15) & ~(size_t)15;
+}
+
 extern "C" size_t mspi_attn_ws_bytes(const MspiAttnDesc* d) {
   if (!d || d->prec != MSPI_PREC_F16X3 || d->B <= 0 || d->Hh <= 0 || d->Nk <= 0) return 0;
-  return (size_t)d->B * d->Hh * 2 * attn_nkp(d) * (size_t)(d->D + d->Dv) * sizeof(_Float16);
+  const int split = attn_ksplit(d);
+  const size_t part = split > 1 ? (size_t)split * d->B * d->Hh * d->Nq * (size_t)(d->Dv + 2) * sizeof(float) : 0;
+  return attn_planes_bytes(d) + part;
 }
 
 static int attn_fwd_impl(const MspiAttnDesc* d, const float* q, const float* k, const float* v, const float* res,
@@ -755,7 +835,7 @@ static int attn_fwd_impl(const MspiAttnDesc* d, const float* q, const float* k, 
   a.q = q; a.k = k; a.v = v; a.res = res; a.biasT = biasT; a.maskT = maskT; a.tok_idx = tok_idx; a.o = o;
   a.B = d->B; a.Hh = d->Hh; a.Nq = d->Nq; a.Nk = d->Nk; a.nmask = d->nmask > 0 ? d->nmask : 1;
   a.nwin = d->nwin > 0 ? d->nwin : 1;
-  a.kp = a.vp = nullptr; a.Nkp = 0;
+  a.kp = a.vp = nullptr; a.Nkp = 0; a.part_o = a.part_ml = nullptr;
   a.q_sB = d->q_sB; a.q_sH = d->q_sH; a.q_sT = d->q_sT;
   a.k_sB = d->k_sB; a.k_sH = d->k_sH; a.k_sT = d->k_sT;
   a.v_sB = d->v_sB; a.v_sH = d->v_sH; a.v_sT = d->v_sT;
@@ -773,11 +853,19 @@ static int attn_fwd_impl(const MspiAttnDesc* d, const float* q, const float* k, 
     // 2.244 ms per forward, better or equal on every shape.  MSPI_ATTN_PF=0 switches it off for an A/B.
     static const char* pf_env = getenv("MSPI_ATTN_PF");
     const bool pf = !(pf_env && pf_env[0] == '0');
+    const int split = (pf && !biasT && !maskT && !tok_idx) ? attn_ksplit(d) : 1;
+    if (split > 1) {
+      a.part_o = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws) + attn_planes_bytes(d));
+      a.part_ml = a.part_o + (size_t)split * d->B * d->Hh * d->Nq * d->Dv;
+      grid.z = (unsigned)split;
+    }
+    const dim3 mgrid((unsigned)(((long)d->B * d->Hh * d->Nq * (d->Dv / 4) + 255) / 256));
 #define MSPI_ATTN_PL(DD, DVV)                                                                        \
   case DD * 1000 + DVV:                                                                              \
     hipLaunchKernelGGL((attn_kv_planes_kernel<DD, DVV>), pgrid, dim3(256), 0, s, a);                 \
     if (pf) hipLaunchKernelGGL((attn_f16x3_kernel<DD, DVV, true, true>), grid, dim3(256), 0, s, a);  \
     else hipLaunchKernelGGL((attn_f16x3_kernel<DD, DVV, true, false>), grid, dim3(256), 0, s, a);    \
+    if (split > 1) hipLaunchKernelGGL((attn_merge_kernel<DVV>), mgrid, dim3(256), 0, s, a, split);   \
     break;
     switch (key) {
       MSPI_ATTN_PL(32, 32) MSPI_ATTN_PL(64, 64) MSPI_ATTN_PL(96, 96) MSPI_ATTN_PL(128, 128) MSPI_ATTN_PL(128, 96) MSPI_ATTN_PL(144, 96) MSPI_ATTN_PL(160, 96)

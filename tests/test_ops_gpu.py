@@ -1,5 +1,6 @@
 """Op-level parity of every C-ABI kernel against a plain PyTorch fp32 CPU reference of the same op.
 (Module- and model-level parity against the oracle / golden fixtures: test_parity_gpu.py.)"""
+import ctypes as C
 import math
 
 import pytest
@@ -749,10 +750,11 @@ def test_f16x3_small_row_beside_normal_rows(dev):
     assert (others.max(1).values / ref.abs().max(1).values[torch.arange(512) != 3]).max().item() < 2e-6
 
 
-@pytest.mark.parametrize("B,H,N,D,win", [(2, 2, 100, 64, False), (3, 4, 392, 32, True), (1, 1, 450, 96, False)])
+@pytest.mark.parametrize("B,H,N,D,win", [(2, 2, 100, 64, False), (3, 4, 392, 32, True), (1, 1, 210, 96, False)])
 def test_attention_planes_bit_identical(dev, B, H, N, D, win):
     """mspi_attn_fwd_ws (K / V split once per head into workspace planes, staged by plain copies) == mspi_attn_fwd (every
-    query tile splits its own copy), bit for bit -- ragged key counts, several heads, a windowed token index."""
+    query tile splits its own copy), bit for bit -- ragged key counts, several heads, a windowed token index.  (Shapes the
+    key split leaves alone: fewer than 24 key tiles, or a token index.)"""
     from mspi_amd import engine as E
     if E.DEFAULT_PREC != E.PREC_F16X3:
         pytest.skip("f16x3 only")
@@ -772,6 +774,37 @@ def test_attention_planes_bit_identical(dev, B, H, N, D, win):
             E.ATTN_PLANES = True
     assert torch.equal(outs[0], outs[1])
 
+
+
+@pytest.mark.parametrize("B,H,N,D", [(1, 1, 900, 96), (2, 2, 1000, 64), (1, 4, 790, 128)])
+def test_attention_key_split(dev, B, H, N, D):
+    """Few-query shapes: mspi_attn_fwd_ws hands slices of the key tiles to gridDim.z workgroups and merges their partial
+    (O, max, sum) in fixed order.  Against torch fp64 softmax attention, against the unsplit kernel, and run-to-run bit
+    equality; ragged last slice and last tile (790 keys = 25 tiles over 2 slices of 13 and 12)."""
+    from mspi_amd import engine as E
+    if E.DEFAULT_PREC != E.PREC_F16X3:
+        pytest.skip("f16x3 only")
+    lib = E._lib.load()
+    d = E.AttnDesc()
+    d.B, d.Hh, d.Nq, d.Nk, d.D, d.Dv, d.prec = B, H, N, N, D, D, E.PREC_F16X3
+    planes = B * H * 2 * ((N + 31) // 32 * 32) * 2 * D * 2
+    assert lib.mspi_attn_ws_bytes(C.byref(d)) > planes + 15, "this shape is meant to engage the key split"
+    g = torch.Generator().manual_seed(N + D)
+    qkv = torch.randn(B * N, 3 * H * D, generator=g)
+    x = E.CL(qkv.to(dev).view(-1), 0, B, 1, 1, N, 3 * H * D, 3 * H * D)
+    q, k, v = (qkv.double().view(B, N, 3, H, D).permute(2, 0, 3, 1, 4)[i] for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1) @ v).permute(0, 2, 1, 3).reshape(B * N, H * D)
+    out = E.attention(x, B, N, H, D, D ** -0.5)
+    got = out.as_rows()[:, : H * D].cpu()
+    _close(got, ref.float(), 2e-5, "key-split attention")
+    out2 = E.attention(x, B, N, H, D, D ** -0.5)
+    assert torch.equal(out.buf, out2.buf)
+    E.ATTN_PLANES = False
+    try:
+        plain = E.attention(x, B, N, H, D, D ** -0.5).as_rows()[:, : H * D].cpu()
+    finally:
+        E.ATTN_PLANES = True
+    _close(got, plain, 2e-6, "key-split vs one pass")
 
 
 def test_range_check_moves_plane_consumer_in_mid_forward(dev):
