@@ -62,10 +62,25 @@ __device__ __forceinline__ float fast_erf(float x) {
   return copysignf(y, x);
 }
 
+// GELU (erf form) u * Phi(u) with the constants of fast_erf folded onto u: q = 0.5 * erfc(|u| / sqrt 2) = t P(t) exp(-u^2 / 2) with
+// t = 1 / (1 + (p / sqrt 2) |u|) and the polynomial's coefficients halved; Phi = 1 - q for u >= 0, q below.  15 VALU instructions
+// (two of them transcendental) against 17 for 0.5 u (1 + erf(u / sqrt 2)); same absolute error on Phi (<= 0.75e-7).
+__device__ __forceinline__ float gelu_erf(float u) {
+  const float au = fabsf(u);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, au, 1.f));
+  const float e = __builtin_amdgcn_exp2f(u * u * (-0.5f * 1.4426950408889634f));
+  float y = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  y = fmaf(y, t, 0.5f * 1.421413741f);
+  y = fmaf(y, t, 0.5f * -0.284496736f);
+  y = fmaf(y, t, 0.5f * 0.254829592f);
+  const float r = u * (y * t * e);          // u q
+  return u >= 0.f ? u - r : r;
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
     case MSPI_ACT_RELU: return fmaxf(v, 0.f);
-    case MSPI_ACT_GELU: return 0.5f * v * (1.f + fast_erf(v * 0.70710678118654752440f));  // nn.GELU (erf form)
+    case MSPI_ACT_GELU: return gelu_erf(v);  // nn.GELU (erf form)
     case MSPI_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
     case MSPI_ACT_SWISH: return v / (1.f + __expf(-v));
     default: return v;

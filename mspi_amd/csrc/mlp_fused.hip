@@ -13,12 +13,19 @@
 //     directly the B operand of phase 2
 //         Y^T[C][32 rows] += W2[:, chunk] . H                          (A operand = weights, B operand = H)
 //     The k-slot -> hidden-unit permutation this implies is absorbed into the (offline) packing of W2.
+//   * the chunk loop is a software pipeline: iteration j holds phase 2 of chunk j-1, the GELU + split of chunk j and phase 1
+//     of chunk j+1 in one hand-interleaved instruction stream (a weight triple of 3 MFMAs in front of each of the 16
+//     accumulator elements' ~20 VALU instructions).  A wave's own VALU work issues in the shadow of its MFMAs at no cost;
+//     an MFMA-phase wave beside a VALU-phase wave on one SIMD slows both (tools/coissue_probe.hip).  Round 3, batch-8
+//     shapes: C = 192 340 -> 302 us, C = 96 303 -> 294 us (that one is bound by the GELU's VALU issue: 390 instructions per
+//     chunk and wave against 36 MFMAs).
 //   * weights are packed in exact fragment order (engine.pack_mlp), so a chunk's weights are one linear 24/48 KB
 //     block: staged by LDS-DMA (global_load_lds, 1 KB per wave instruction, no swizzle needed) into a ring of NS
 //     stages, read back with conflict-free ds_read_b128 (lane*16 B).  No activation ever goes through LDS.
 //   * epilogue: Y^T accumulators -> +bias, +residual -> 16-B stores (4 consecutive channels per lane).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace mspi {
 
@@ -40,7 +47,7 @@ struct MlpArgs {
 //   W1 part: [ks = 0..C/16)[plane hi,lo][lane][e]   = W1s[j*32 + lane%32][16*ks + 8*(lane/32) + e]
 //   W2 part: [s = 0..2)[ct = 0..C/32)[plane][lane][e] = W2s[ct*32 + lane%32][j*32 + (2*s + e/4)*8 + 4*(lane/32) + e%4]
 template <int C, int TM, int NS>
-__global__ __launch_bounds__(256, (C == 96 && TM == 1) ? (NS == 2 ? 3 : 2) : 1) void mlp_fused_kernel(const MlpArgs p) {
+__global__ __launch_bounds__(256, (C == 96 && TM == 1) ? 2 : 1) void mlp_fused_kernel(const MlpArgs p) {
   constexpr int KS = C / 16, CT = C / 32;
   constexpr int W1B = KS * 2048, W2B = 2 * CT * 2048, SB = W1B + W2B;   // bytes per stage
   constexpr int DPW = SB / 4096;                                        // DMA instructions per wave per stage
@@ -53,12 +60,37 @@ __global__ __launch_bounds__(256, (C == 96 && TM == 1) ? (NS == 2 ? 3 : 2) : 1) 
   const int li = lane & 31, lh = lane >> 5;
   const long row0 = (long)blockIdx.x * BM + wave * (32 * TM);
 
+  // Software pipeline over the hidden chunks.  Iteration j holds, in ONE scheduling region of the wave,
+  //     phase 2 of chunk j-1 (MFMA)  |  GELU + split of chunk j (VALU, ~24 instructions per hidden unit and lane)  |  phase 1 of chunk j+1 (MFMA)
+  // because on this chip a wave's own VALU instructions issue for free in the shadow of its MFMAs, while an MFMA-phase wave
+  // and a VALU-phase wave sharing a SIMD slow each other to less than the sum (tools/coissue_probe.hip: MFMA + 8 FMA
+  // interleaved in one wave 42 cycles per pair = the VALU's own 41.5; split over two waves of a SIMD 78 / 110).
+  // Ring stage j therefore holds W2 of chunk j and W1 of chunk j + 2 and is consumed by iteration j + 1.  The packing is
+  // unchanged -- the W1 half of a stage is fetched from two chunks on (the last stages re-fetch chunk 0's, unused, so that
+  // every wave's DMA count stays the same).
+  static_assert(W1B % (DPW * 1024) == 0, "the W1 / W2 boundary of a stage falls between waves");
   auto issue_stage = [&](int j) {
-    const unsigned char* src = p.wp + (long)j * SB + (wave * DPW) * 1024 + lane * 16;
+    const bool w1 = wave * DPW * 1024 < W1B;
+    const int jc = w1 ? (j + 2 < p.nch ? j + 2 : 0) : j;
+    const unsigned char* src = p.wp + (long)jc * SB + (wave * DPW) * 1024 + lane * 16;
     unsigned char* dst = smem + (j % NS) * SB + (wave * DPW) * 1024;
 #pragma unroll
     for (int d = 0; d < DPW; ++d)
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src + d * 1024), (lds_void*)(dst + d * 1024), 16, 0, 0);
+  };
+  // W1 of chunks 0 and 1 go to the two halves of the last slot (W1B == W2B), which the ring first overwrites at the top of
+  // iteration 1, after both have been consumed (prologue, iteration 0)
+  static_assert(W1B == W2B, "the prologue parks W1 of chunk 1 in a W2 half");
+  constexpr int DP0 = W1B / 4096;
+  auto issue_w1_01 = [&]() {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int jc = c < p.nch ? c : 0;
+#pragma unroll
+      for (int d = 0; d < DP0; ++d)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(p.wp + (long)jc * SB + (wave * DP0 + d) * 1024 + lane * 16),
+                                         (lds_void*)(smem + (NS - 1) * SB + c * W1B + (wave * DP0 + d) * 1024), 16, 0, 0);
+    }
   };
 
   // ---- rows: load (clamped), LayerNorm, split.  lane (li, lh) holds row li of each row group, k = 16ks + 8lh + e
@@ -77,7 +109,9 @@ __global__ __launch_bounds__(256, (C == 96 && TM == 1) ? (NS == 2 ? 3 : 2) : 1) 
     }
   }
   // weight ring prologue + bias staging fly under the LayerNorm
-  for (int j = 0; j < NS - 1 && j < p.nch; ++j) issue_stage(j);
+  static_assert(NS >= 3, "the pipeline keeps stage j-1 in use while stage j is in flight and the prologue's slot is live");
+  issue_w1_01();
+  for (int j = 0; j < NS - 1; ++j) issue_stage(j < p.nch ? j : 0);     // always NS-1 stages: uniform DMA counts
   for (int i = tid; i < p.nch * 32; i += 256) b1s[i] = p.b1[i];
 
   if (p.ln) {
@@ -136,34 +170,15 @@ __global__ __launch_bounds__(256, (C == 96 && TM == 1) ? (NS == 2 ? 3 : 2) : 1) 
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[t][ct][i] = 0.f;
 
-  for (int j = 0; j < p.nch; ++j) {
-    // stage j has landed (mine: counted vmcnt, the newer NS-2 stages may stay in flight; everybody's: barrier);
-    // the barrier also says every wave is done reading stage j-1, whose slot the next DMA overwrites.
-    if (j + NS - 2 < p.nch) {
-      if (NS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if ((NS - 2) * DPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if ((NS - 2) * DPW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if ((NS - 2) * DPW == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-      else if ((NS - 2) * DPW == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (j + NS - 1 < p.nch) issue_stage(j + NS - 1);
-
-    const unsigned char* st = smem + (j % NS) * SB + lane * 16;
-    // ---- phase 1: H^T chunk
-    v16f h[TM];
+  auto phase1 = [&](const unsigned char* w1, v16f (&h)[TM]) {
 #pragma unroll
     for (int t = 0; t < TM; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) h[t][i] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const v8h wh = *reinterpret_cast<const v8h*>(st + (ks * 2 + 0) * 1024);
-      const v8h wl = *reinterpret_cast<const v8h*>(st + (ks * 2 + 1) * 1024);
+      const v8h wh = *reinterpret_cast<const v8h*>(w1 + (ks * 2 + 0) * 1024);
+      const v8h wl = *reinterpret_cast<const v8h*>(w1 + (ks * 2 + 1) * 1024);
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
         if (!kSingleProduct) {
@@ -173,32 +188,120 @@ __global__ __launch_bounds__(256, (C == 96 && TM == 1) ? (NS == 2 ? 3 : 2) : 1) 
         h[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[t][ks], h[t], 0, 0, 0);
       }
     }
-    // ---- bias + activation + split: acc index i <-> hidden unit (i/4)*8 + 4*lh + i%4 of the chunk
+  };
+  // One pipeline iteration, hand-interleaved: the GELU + split of chunk j is cut into its 16 accumulator elements, and in
+  // front of element g sit the weight triples (3 MFMAs on one pair of hi/lo weight fragments) [g*NTR/16, (g+1)*NTR/16) of
+  //   phase 2 of chunk j-1 (triples 0 .. 2CT-1: (s, ct))   and   phase 1 of chunk j+1 (triples 2CT .. 2CT+KS-1: ks),
+  // each group closed by a sched_barrier so the order survives the compiler.  The fragments of the next triple are read
+  // from LDS one group ahead.
+  v16f h[TM], hn[TM];
+  v8h hh[TM][2], hl[TM][2], gh[TM][2], gl[TM][2];
+  auto body = [&](auto has_p2, auto has_p1, int j, const unsigned char* st) {
+    constexpr bool P2 = decltype(has_p2)::value, P1 = decltype(has_p1)::value;
+    constexpr int T0 = P2 ? 0 : 2 * CT, T1 = P1 ? 2 * CT + KS : 2 * CT, NTR = T1 - T0;
+    auto frag = [&](int tr, int plane) {
+      const unsigned char* base = tr < 2 * CT ? st + W1B + (tr * 2) * 1024 : st + ((tr - 2 * CT) * 2) * 1024;
+      return *reinterpret_cast<const v8h*>(base + plane * 1024);
+    };
     float bv[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 b = *reinterpret_cast<const float4*>(b1s + j * 32 + q * 8 + 4 * lh);
       bv[q * 4 + 0] = b.x; bv[q * 4 + 1] = b.y; bv[q * 4 + 2] = b.z; bv[q * 4 + 3] = b.w;
     }
-    v8h hh[TM][2], hl[TM][2];
+    v8h wh, wl, nh, nl;
+    if (NTR > 0) { wh = frag(T0, 0); wl = frag(T0, 1); }
 #pragma unroll
-    for (int t = 0; t < TM; ++t)
+    for (int g = 0; g < 16; ++g) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float u = fmaf(h[t][i], p.inv_s1, bv[i]);
-        const float v = 0.5f * u * (1.f + fast_erf(u * 0.70710678118654752440f));   // nn.GELU (erf form)
+      for (int tr = T0 + g * NTR / 16; tr < T0 + (g + 1) * NTR / 16; ++tr) {
+        if (tr + 1 < T1) { nh = frag(tr + 1, 0); nl = frag(tr + 1, 1); }
+        __builtin_amdgcn_sched_barrier(0);      // the reads stay HERE: a whole group ahead of the MFMAs that wait for them
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          if (tr < 2 * CT) {
+            const int s = tr / CT, ct = tr % CT;
+            if (!kSingleProduct) {
+              o[t][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hh[t][s], o[t][ct], 0, 0, 0);
+              o[t][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hl[t][s], o[t][ct], 0, 0, 0);
+            }
+            o[t][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hh[t][s], o[t][ct], 0, 0, 0);
+          } else {
+            const int ks = tr - 2 * CT;
+            const v16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (!kSingleProduct) {
+              hn[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[t][ks], ks == 0 ? zero : hn[t], 0, 0, 0);   // inline-constant C: no zero fill
+              hn[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[t][ks], hn[t], 0, 0, 0);
+              hn[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[t][ks], hn[t], 0, 0, 0);
+            } else {
+              hn[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[t][ks], ks == 0 ? zero : hn[t], 0, 0, 0);
+            }
+          }
+        }
+        wh = nh; wl = nl;
+      }
+      // bias + activation + split of element g: acc index g <-> hidden unit (g/4)*8 + 4*lh + g%4 of the chunk
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const float u = fmaf(h[t][g], p.inv_s1, bv[g]);
+        const float v = gelu_erf(u);              // nn.GELU (erf form)
         _Float16 f, l;
         split_f16(v, f, l);
-        hh[t][i >> 3][i & 7] = f;
-        hl[t][i >> 3][i & 7] = l;
+        gh[t][g >> 3][g & 7] = f;
+        gl[t][g >> 3][g & 7] = l;
       }
-    // ---- phase 2: Y^T += W2[:, chunk] . H
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      if (P1) h[t] = hn[t];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) { hh[t][s] = gh[t][s]; hl[t][s] = gl[t][s]; }
+    }
+  };
+  using yes = std::true_type;
+  using no = std::false_type;
+
+  // chunks 0 and 1's W1 have landed when only the ring prologue's NS-1 stages are outstanding
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * DPW) : "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  phase1(smem + (NS - 1) * SB + lane * 16, h);
+  // iteration 0: GELU of chunk 0 beside phase 1 of chunk 1 (whose W1 sits in the W2 half of the prologue's slot: the body
+  // addresses phase-1 fragments relative to a stage base, so hand it the base that puts them there)
+  if (p.nch > 1) body(no(), yes(), 0, smem + (NS - 1) * SB + W1B + lane * 16);
+  else body(no(), no(), 0, smem + lane * 16);
+
+  // top of iteration j >= 1: stage j-1 has landed (mine: counted vmcnt, the NS-2 stages behind it stay in flight;
+  // everybody's: barrier); the barrier also says every wave is done with what iteration j-1 read (stage j-2, or the
+  // prologue's slot), which the next DMA overwrites
+  auto top = [&](int j) {
+    if (j + NS - 3 < p.nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * DPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (j + NS - 2 < p.nch) issue_stage(j + NS - 2);
+  };
+  int j = 1;
+#pragma unroll 2
+  for (; j + 1 < p.nch; ++j) {
+    top(j);
+    body(yes(), yes(), j, smem + ((j - 1) % NS) * SB + lane * 16);
+  }
+  if (j < p.nch) {      // j = nch - 1 (nch >= 2): no chunk j + 1
+    top(j);
+    body(yes(), no(), j, smem + ((j - 1) % NS) * SB + lane * 16);
+    ++j;
+  }
+  top(j);               // j = nch: phase 2 of the last chunk
+  {
+    const unsigned char* w2 = smem + ((j - 1) % NS) * SB + lane * 16 + W1B;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        const v8h wh = *reinterpret_cast<const v8h*>(st + W1B + ((s * CT + ct) * 2 + 0) * 1024);
-        const v8h wl = *reinterpret_cast<const v8h*>(st + W1B + ((s * CT + ct) * 2 + 1) * 1024);
+        const v8h wh = *reinterpret_cast<const v8h*>(w2 + ((s * CT + ct) * 2 + 0) * 1024);
+        const v8h wl = *reinterpret_cast<const v8h*>(w2 + ((s * CT + ct) * 2 + 1) * 1024);
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
           if (!kSingleProduct) {
@@ -280,7 +383,7 @@ extern "C" int mspi_mlp_fwd(const MspiMlpDesc* d, const void* x, const void* gam
   int rc;
   MSPI_REQUIRE(d->C != 96 || d->hidden <= 512, "mspi_mlp_fwd: hidden = %d > 512 with C = 96", d->hidden);
   if (d->C == 96) rc = (variant == 2) ? launch_mlp<96, 2, 4>(a, (hipStream_t)stream) :
-                       (variant == 3) ? launch_mlp<96, 1, 2>(a, (hipStream_t)stream) : launch_mlp<96, 1, 3>(a, (hipStream_t)stream);
+                       launch_mlp<96, 1, 3>(a, (hipStream_t)stream);
   else rc = launch_mlp<192, 1, 3>(a, (hipStream_t)stream);
   (void)rc;
   return check_launch("mspi_mlp_fwd");
