@@ -556,6 +556,272 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_kernel(const AttnArgs p) {
   }
 }
 
+// ------------------------------------------------------------------ the same kernel as a software pipeline over the key tiles
+// attn_f16x3_kernel alternates, per wave, an MFMA phase (S), a VALU phase (softmax) and an MFMA phase (PV).  On this chip a
+// wave's own VALU instructions issue in the shadow of its MFMAs for free, while an MFMA-phase wave and a VALU-phase wave that
+// share a SIMD slow each other to less than the sum (tools/coissue_probe.hip, profiles/r03_coissue_probe.txt) -- so the
+// second workgroup per CU hides almost nothing (a CU retires one 128 x 32 step per ~3.3 us however many share it).
+// Here iteration t holds, in one hand-interleaved instruction stream per wave,
+//     S of tile t+1 (MFMA)  ||  softmax of tile t (VALU)      then      PV of tile t (MFMA)  ||  staging of K(t+2), V(t+1)
+// Each MFMA triple (3 split products on one operand pair) is followed by a slice of the VALU / staging work and closed by a
+// sched_barrier so that the order survives the compiler; operand fragments are read from LDS one triple ahead.  K tiles run
+// one tile ahead of V tiles in the LDS double buffers.  Planes + prefetch path only (no bias, mask or token index); the
+// arithmetic per query row is that of attn_f16x3_kernel (same products, same order), so results are bit-identical.
+template <int D, int DV>
+__global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
+  constexpr int KP = D + 8, VP = 36, NS = D / 16, NT = DV / 32;
+  constexpr float QSC = 64.f, KSC = ATT_KSC, PSC = ATT_PSC, VSC = ATT_VSC;
+  constexpr int KT = 2 * 32 * KP, VT = 2 * DV * VP;       // halves per staged K / V tile (hi + lo planes)
+  __shared__ __attribute__((aligned(16))) _Float16 smem[2 * KT + 2 * VT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y / p.Hh, h = blockIdx.y % p.Hh;
+  const int q = blockIdx.x * 128 + wave * 32 + li;
+  const bool qok = q < p.Nq;
+
+  v8h qh[NS], ql[NS];
+  {
+    const float* qp = p.q + (long)b * p.q_sB + (long)h * p.q_sH + (long)(qok ? q : 0) * p.q_sT + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      float4 a = *reinterpret_cast<const float4*>(qp + 16 * s);
+      float4 c = *reinterpret_cast<const float4*>(qp + 16 * s + 4);
+      if (!qok) { a = make_float4(0.f, 0.f, 0.f, 0.f); c = a; }
+      const float f[8] = {a.x * QSC, a.y * QSC, a.z * QSC, a.w * QSC, c.x * QSC, c.y * QSC, c.z * QSC, c.w * QSC};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        _Float16 hh, ll;
+        split_f16(f[e], hh, ll);
+        qh[s][e] = hh; ql[s][e] = ll;
+      }
+    }
+  }
+  v16f acc[NT], sc, scn;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f, m_new = 0.f, alpha = 1.f, psum = 0.f;
+  v8h ph[2], pl[2];
+
+  constexpr int PFK = (32 * (D / 8) + 255) / 256, PFV = (DV * 4 + 255) / 256;
+  uint4 pf_kh[PFK], pf_kl[PFK], pf_vh[PFV], pf_vl[PFV];
+  auto prefetch_k = [&](int k0) {
+    const _Float16* gKh = p.kp + (long)blockIdx.y * 2 * p.Nkp * D + (long)k0 * D;
+    const _Float16* gKl = gKh + (long)p.Nkp * D;
+#pragma unroll
+    for (int i = 0; i < PFK; ++i) {
+      const int idx = tid + 256 * i;
+      const int ii = idx < 32 * (D / 8) ? idx : 0;            // a K tile is one contiguous run of 32 * D halves per plane
+      pf_kh[i] = *reinterpret_cast<const uint4*>(gKh + 8 * ii);
+      pf_kl[i] = *reinterpret_cast<const uint4*>(gKl + 8 * ii);
+    }
+  };
+  auto prefetch_v = [&](int k0) {
+    const _Float16* gVh = p.vp + (long)blockIdx.y * 2 * DV * p.Nkp + k0;
+    const _Float16* gVl = gVh + (long)DV * p.Nkp;
+#pragma unroll
+    for (int i = 0; i < PFV; ++i) {
+      const int idx = tid + 256 * i;
+      const int ii = idx < DV * 4 ? idx : 0;
+      const int d = ii >> 2, c = ii & 3;
+      pf_vh[i] = *reinterpret_cast<const uint4*>(gVh + (long)d * p.Nkp + 8 * c);
+      pf_vl[i] = *reinterpret_cast<const uint4*>(gVl + (long)d * p.Nkp + 8 * c);
+    }
+  };
+  auto stage_k = [&](_Float16* bK) {
+#pragma unroll
+    for (int i = 0; i < PFK; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < 32 * (D / 8)) {
+        const int row = idx / (D / 8), c = idx - row * (D / 8);
+        *reinterpret_cast<uint4*>(&bK[row * KP + 8 * c]) = pf_kh[i];
+        *reinterpret_cast<uint4*>(&bK[32 * KP + row * KP + 8 * c]) = pf_kl[i];
+      }
+    }
+  };
+  auto stage_v = [&](_Float16* bV) {
+#pragma unroll
+    for (int i = 0; i < PFV; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < DV * 4) {
+        const int d = idx >> 2, c = idx & 3;
+        *reinterpret_cast<uint2*>(&bV[d * VP + 8 * c]) = make_uint2(pf_vh[i].x, pf_vh[i].y);
+        *reinterpret_cast<uint2*>(&bV[d * VP + 8 * c + 4]) = make_uint2(pf_vh[i].z, pf_vh[i].w);
+        *reinterpret_cast<uint2*>(&bV[DV * VP + d * VP + 8 * c]) = make_uint2(pf_vl[i].x, pf_vl[i].y);
+        *reinterpret_cast<uint2*>(&bV[DV * VP + d * VP + 8 * c + 4]) = make_uint2(pf_vl[i].z, pf_vl[i].w);
+      }
+    }
+  };
+
+  int kbeg = 0, kend = p.Nk;
+  if (gridDim.z > 1) {
+    const int ntile = (p.Nk + 31) >> 5, tps = (ntile + gridDim.z - 1) / gridDim.z;
+    kbeg = blockIdx.z * tps * 32;
+    kend = min(p.Nk, kbeg + tps * 32);
+  }
+  const int nt = (kend - kbeg + 31) >> 5;
+  _Float16* const Kb = smem;
+  _Float16* const Vb = smem + 2 * KT;
+  // prologue: K(0), V(0), K(1) staged; K(2) and V(1) on their way in the prefetch registers
+  prefetch_k(kbeg);
+  prefetch_v(kbeg);
+  stage_k(Kb);
+  stage_v(Vb);
+  if (nt > 1) { prefetch_k(kbeg + 32); stage_k(Kb + KT); }
+  if (nt > 2) prefetch_k(kbeg + 64);
+  if (nt > 1) prefetch_v(kbeg + 32);
+  __syncthreads();
+
+  const float sscale = p.scale * (1.4426950408889634f / (QSC * KSC));
+  // S^T = K . Q^T from a staged K tile (NS triples); behind triple st runs slice(st)
+  auto region_s = [&](v16f& s, const _Float16* K, auto&& slice) {
+    const _Float16* Kl = K + 32 * KP;
+    // fragments are read TWO triples ahead: a ds_read_b128 issued one triple (96 cycles) ahead is not back in time
+    auto kf = [&](int st, const _Float16* P) { return *reinterpret_cast<const v8h*>(&P[li * KP + 16 * st + 8 * lh]); };
+    v8h kh = kf(0, K), kl = kf(0, Kl), kh1 = kh, kl1 = kl;
+    if (NS > 1) { kh1 = kf(1, K); kl1 = kf(1, Kl); }
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      v8h nh = kh1, nl = kl1;
+      if (st + 2 < NS) { nh = kf(st + 2, K); nl = kf(st + 2, Kl); }
+      __builtin_amdgcn_sched_barrier(0);
+      const v16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (!kSingleProduct) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], st == 0 ? zero : s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], s, 0, 0, 0);
+      } else {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], st == 0 ? zero : s, 0, 0, 0);
+      }
+      slice(st);
+      kh = kh1; kl = kl1; kh1 = nh; kl1 = nl;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // slice i of the online softmax over this tile's 32 keys (16 in my registers, 16 in lane^32's): 0 scale (+ mask of the keys
+  // past the end), 1 running maximum and rescale factor, 2..17 one probability each (exp2, sum, split), 18 the sum
+  constexpr int NPC = 19;
+  auto sm_piece = [&](int i, int k0) {
+    if (i == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] *= sscale;
+      if (k0 + 32 > p.Nk) {      // only the last tile has keys past the end (wave-uniform branch)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (k0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= p.Nk) sc[r] = -INFINITY;
+      }
+    } else if (i == 1) {
+      float mt = sc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sc[r]);
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      m_new = fmaxf(m_run, mt);
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      psum = 0.f;
+    } else if (i < 18) {
+      const int r = i - 2;
+      const float e = __builtin_amdgcn_exp2f(sc[r] - m_new);
+      psum += e;
+      _Float16 hi, lo;
+      split_f16(e * PSC, hi, lo);
+      ph[r >> 3][r & 7] = hi;
+      pl[r >> 3][r & 7] = lo;
+    } else {
+      const float ps = psum + __shfl_xor(psum, 32, 64);
+      l_run = l_run * alpha + ps;
+    }
+  };
+
+  region_s(sc, Kb, [](int) {});
+  for (int t = 0; t < nt; ++t) {
+    const int k0 = kbeg + 32 * t;
+    // ---- S of tile t+1 with the softmax of tile t behind its triples
+    if (t + 1 < nt) {
+      region_s(scn, Kb + ((t + 1) & 1) * KT, [&](int st) {
+#pragma unroll
+        for (int i = st * NPC / NS; i < (st + 1) * NPC / NS; ++i) sm_piece(i, k0);
+      });
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPC; ++i) sm_piece(i, k0);
+    }
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {      // no row of this wave raised its maximum: nothing to rescale
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] *= alpha;
+    }
+    // ---- PV of tile t with the staging of K(t+2), V(t+1) and the next prefetch behind its triples
+    {
+      const _Float16* Vh = Vb + (t & 1) * VT;
+      const _Float16* Vl = Vh + DV * VP;
+      auto vfrag = [&](int tr, const _Float16* V) {
+        const int s2 = tr / NT, u = tr % NT, d = u * 32 + li;
+        const v4h a0 = *reinterpret_cast<const v4h*>(&V[d * VP + 16 * s2 + 4 * lh]);
+        const v4h a1 = *reinterpret_cast<const v4h*>(&V[d * VP + 16 * s2 + 8 + 4 * lh]);
+        const v8h v = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        return v;
+      };
+      v8h vh = vfrag(0, Vh), vl = vfrag(0, Vl), vh1 = vh, vl1 = vl;
+      if (2 * NT > 1) { vh1 = vfrag(1, Vh); vl1 = vfrag(1, Vl); }
+#pragma unroll
+      for (int tr = 0; tr < 2 * NT; ++tr) {
+        v8h nh = vh1, nl = vl1;
+        if (tr + 2 < 2 * NT) { nh = vfrag(tr + 2, Vh); nl = vfrag(tr + 2, Vl); }
+        __builtin_amdgcn_sched_barrier(0);
+        const int s2 = tr / NT, u = tr % NT;
+        if (!kSingleProduct) {
+          acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s2], acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s2], acc[u], 0, 0, 0);
+        }
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s2], acc[u], 0, 0, 0);
+        constexpr int LT = 2 * NT - 1;                                          // (DV = 32 has only two triples)
+        if (tr == 0 && t + 2 < nt) stage_k(Kb + (t & 1) * KT);                 // K(t) was consumed in iteration t-1
+        if (tr == (LT < 1 ? LT : 1) && t + 1 < nt) stage_v(Vb + ((t + 1) & 1) * VT);   // V(t-1) too
+        if (tr == (LT < 2 ? LT : 2) && t + 3 < nt) prefetch_k(k0 + 96);
+        if (tr == (LT < 3 ? LT : 3) && t + 2 < nt) prefetch_v(k0 + 64);
+        vh = vh1; vl = vl1; vh1 = nh; vl1 = nl;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();          // tile t consumed by every wave; K(t+2), V(t+1) visible
+    sc = scn;
+  }
+
+  if (gridDim.z > 1) {
+    if (qok) {
+      const long pr = ((long)blockIdx.z * gridDim.y + blockIdx.y) * p.Nq + q;
+      if (lh == 0) *reinterpret_cast<float2*>(p.part_ml + pr * 2) = make_float2(m_run, l_run);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(p.part_o + pr * DV + t * 32 + 8 * g + 4 * lh) =
+              make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+    }
+    return;
+  }
+  if (qok) {
+    const float inv = 1.f / (l_run * (PSC * VSC));
+    const long oo = (long)b * p.o_sB + (long)h * p.o_sH + (long)q * p.o_sT;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 o4 = make_float4(acc[t][4 * g] * inv, acc[t][4 * g + 1] * inv, acc[t][4 * g + 2] * inv,
+                                acc[t][4 * g + 3] * inv);
+        const int dd = t * 32 + 8 * g + 4 * lh;
+        if (p.res) {
+          const float4 rr = *reinterpret_cast<const float4*>(p.res + oo + dd);
+          o4.x += rr.x; o4.y += rr.y; o4.z += rr.z; o4.w += rr.w;
+        }
+        *reinterpret_cast<float4*>(p.o + oo + dd) = o4;
+      }
+  }
+}
+
 // Key split, second pass: the slices' partial results are merged in fixed order z = 0, 1, .. (deterministic):
 //   M = max_z m_z,  w_z = 2^(m_z - M),  O = sum_z w_z O_z / (PSC VSC sum_z w_z l_z)  (+ res)
 template <int DV>
@@ -853,6 +1119,9 @@ static int attn_fwd_impl(const MspiAttnDesc* d, const float* q, const float* k, 
     // 2.244 ms per forward, better or equal on every shape.  MSPI_ATTN_PF=0 switches it off for an A/B.
     static const char* pf_env = getenv("MSPI_ATTN_PF");
     const bool pf = !(pf_env && pf_env[0] == '0');
+    // software-pipelined form (attn_pipe_kernel) wherever there is no bias, mask or token index; MSPI_ATTN_PIPE=0: off
+    static const char* pipe_env = getenv("MSPI_ATTN_PIPE");
+    const bool pipe = pf && !biasT && !maskT && !tok_idx && !(pipe_env && pipe_env[0] == '0');
     const int split = (pf && !biasT && !maskT && !tok_idx) ? attn_ksplit(d) : 1;
     if (split > 1) {
       a.part_o = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws) + attn_planes_bytes(d));
@@ -863,7 +1132,8 @@ static int attn_fwd_impl(const MspiAttnDesc* d, const float* q, const float* k, 
 #define MSPI_ATTN_PL(DD, DVV)                                                                        \
   case DD * 1000 + DVV:                                                                              \
     hipLaunchKernelGGL((attn_kv_planes_kernel<DD, DVV>), pgrid, dim3(256), 0, s, a);                 \
-    if (pf) hipLaunchKernelGGL((attn_f16x3_kernel<DD, DVV, true, true>), grid, dim3(256), 0, s, a);  \
+    if (pipe) hipLaunchKernelGGL((attn_pipe_kernel<DD, DVV>), grid, dim3(256), 0, s, a);            \
+    else if (pf) hipLaunchKernelGGL((attn_f16x3_kernel<DD, DVV, true, true>), grid, dim3(256), 0, s, a);  \
     else hipLaunchKernelGGL((attn_f16x3_kernel<DD, DVV, true, false>), grid, dim3(256), 0, s, a);    \
     if (split > 1) hipLaunchKernelGGL((attn_merge_kernel<DVV>), mgrid, dim3(256), 0, s, a, split);   \
     break;
