@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 //     fragment is two 8-byte reads of row d (keys 16s+4h .. +3 and 16s+8+4h .. +3).
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ void split4(const float4 v, v4h& hi, v4h& lo) {
   const float a[4] = {v.x, v.y, v.z, v.w};
@@ -219,7 +220,16 @@ constexpr float ATT_KSC = 16.f, ATT_VSC = 16.f, ATT_PSC = 1024.f;
 // that head (196 workgroups at Nq = 25088) used to redo this split on its own copy -- ~200 VALU instructions per thread and
 // 32-key step, beside ~60 MFMAs.  One workgroup per 32-key tile; same arithmetic as the in-kernel staging, so the planes
 // hold bit for bit what attn_f16x3_kernel<.., false> puts into LDS.
-template <int D, int DV>
+// IMG: the planes are written as per-tile LDS IMAGES -- for each (sequence, head) and 32-key tile the K tile [hi, lo][32][D + 8]
+// and the V^T tile [hi, lo][DV][36] exactly as attn_pipe_kernel keeps them in LDS (row pads included, the V image rounded up to
+// a multiple of 1 KB), each one contiguous, so that a tile is staged by plain 1-KB LDS-DMA pieces.
+template <int D, int DV> struct AttnImg {
+  static constexpr int KP = D + 8, VP = 36;
+  static constexpr int KTI = 2 * 32 * KP;                               // halves per K image (a multiple of 512: whole KB)
+  static constexpr int VTI = (2 * DV * VP * 2 + 1023) / 1024 * 512;     // halves per V image, rounded up to whole KB
+};
+
+template <int D, int DV, bool IMG = false>
 __global__ __launch_bounds__(256) void attn_kv_planes_kernel(const AttnArgs p) {
   const int tid = threadIdx.x;
   const int b = blockIdx.y / p.Hh, h = blockIdx.y % p.Hh;
@@ -228,10 +238,14 @@ __global__ __launch_bounds__(256) void attn_kv_planes_kernel(const AttnArgs p) {
   const int* tix = p.tok_idx ? p.tok_idx + (long)(b % p.nwin) * p.Nk : nullptr;
   const float* kb = p.k + (long)sample * p.k_sB + (long)h * p.k_sH;
   const float* vb = p.v + (long)sample * p.v_sB + (long)h * p.v_sH;
-  _Float16* Kh = p.kp + (long)blockIdx.y * 2 * p.Nkp * D;
-  _Float16* Kl = Kh + (long)p.Nkp * D;
-  _Float16* Vh = p.vp + (long)blockIdx.y * 2 * DV * p.Nkp;
-  _Float16* Vl = Vh + (long)DV * p.Nkp;
+  typedef AttnImg<D, DV> I;
+  const long tile = (long)blockIdx.y * (p.Nkp >> 5) + blockIdx.x;
+  // plain layout: planes [hi, lo][Nkp][D] and [hi, lo][DV][Nkp] per (sequence, head); row / column index includes k0
+  _Float16* Kh = IMG ? p.kp + tile * I::KTI - (long)k0 * I::KP : p.kp + (long)blockIdx.y * 2 * p.Nkp * D;
+  _Float16* Kl = IMG ? Kh + 32 * I::KP : Kh + (long)p.Nkp * D;
+  _Float16* Vh = IMG ? p.vp + tile * I::VTI - k0 : p.vp + (long)blockIdx.y * 2 * DV * p.Nkp;
+  _Float16* Vl = IMG ? Vh + DV * I::VP : Vh + (long)DV * p.Nkp;
+  const long kpitch = IMG ? I::KP : D, vpitch = IMG ? I::VP : p.Nkp;
   for (int idx = tid; idx < 32 * (D / 4); idx += 256) {
     const int row = idx / (D / 4), c4 = idx - row * (D / 4);
     const bool ok = k0 + row < p.Nk;
@@ -240,8 +254,8 @@ __global__ __launch_bounds__(256) void attn_kv_planes_kernel(const AttnArgs p) {
     kv = ok ? make_float4(kv.x * ATT_KSC, kv.y * ATT_KSC, kv.z * ATT_KSC, kv.w * ATT_KSC) : make_float4(0.f, 0.f, 0.f, 0.f);
     v4h hi, lo;
     split4(kv, hi, lo);
-    *reinterpret_cast<v4h*>(&Kh[(long)(k0 + row) * D + c4 * 4]) = hi;
-    *reinterpret_cast<v4h*>(&Kl[(long)(k0 + row) * D + c4 * 4]) = lo;
+    *reinterpret_cast<v4h*>(&Kh[(long)(k0 + row) * kpitch + c4 * 4]) = hi;
+    *reinterpret_cast<v4h*>(&Kl[(long)(k0 + row) * kpitch + c4 * 4]) = lo;
   }
   for (int idx = tid; idx < 16 * (DV / 4); idx += 256) {
     const int kp = idx & 15, c4 = idx >> 4;
@@ -261,8 +275,8 @@ __global__ __launch_bounds__(256) void attn_kv_planes_kernel(const AttnArgs p) {
       v2h ph, pl;
       ph[0] = h0[j]; ph[1] = h1[j];
       pl[0] = l0[j]; pl[1] = l1[j];
-      *reinterpret_cast<v2h*>(&Vh[(long)(c4 * 4 + j) * p.Nkp + k0 + 2 * kp]) = ph;
-      *reinterpret_cast<v2h*>(&Vl[(long)(c4 * 4 + j) * p.Nkp + k0 + 2 * kp]) = pl;
+      *reinterpret_cast<v2h*>(&Vh[(long)(c4 * 4 + j) * vpitch + k0 + 2 * kp]) = ph;
+      *reinterpret_cast<v2h*>(&Vl[(long)(c4 * 4 + j) * vpitch + k0 + 2 * kp]) = pl;
     }
   }
 }
@@ -571,7 +585,9 @@ template <int D, int DV>
 __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
   constexpr int KP = D + 8, VP = 36, NS = D / 16, NT = DV / 32;
   constexpr float QSC = 64.f, KSC = ATT_KSC, PSC = ATT_PSC, VSC = ATT_VSC;
-  constexpr int KT = 2 * 32 * KP, VT = 2 * DV * VP;       // halves per staged K / V tile (hi + lo planes)
+  typedef AttnImg<D, DV> I;
+  static_assert(I::KP == KP && I::VP == VP, "LDS layout = plane image layout");
+  constexpr int KT = I::KTI, VT = I::VTI;                 // halves per staged K / V tile (hi + lo planes) = the plane images
   __shared__ __attribute__((aligned(16))) _Float16 smem[2 * KT + 2 * VT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -604,53 +620,26 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
   float m_run = -INFINITY, l_run = 0.f, m_new = 0.f, alpha = 1.f, psum = 0.f;
   v8h ph[2], pl[2];
 
-  constexpr int PFK = (32 * (D / 8) + 255) / 256, PFV = (DV * 4 + 255) / 256;
-  uint4 pf_kh[PFK], pf_kl[PFK], pf_vh[PFV], pf_vl[PFV];
-  auto prefetch_k = [&](int k0) {
-    const _Float16* gKh = p.kp + (long)blockIdx.y * 2 * p.Nkp * D + (long)k0 * D;
-    const _Float16* gKl = gKh + (long)p.Nkp * D;
+  // a tile image is staged as whole 1-KB LDS-DMA pieces (global_load_lds, 16 B per lane), dealt round-robin to the 4 waves:
+  // no registers, no LDS writes, and the data lands while the wave computes
+  const _Float16* const gK = p.kp + (long)blockIdx.y * (p.Nkp >> 5) * KT;
+  const _Float16* const gV = p.vp + (long)blockIdx.y * (p.Nkp >> 5) * VT;
+  auto dma_k = [&](int tile, _Float16* dst) {
+    const _Float16* src = gK + (long)tile * KT;
 #pragma unroll
-    for (int i = 0; i < PFK; ++i) {
-      const int idx = tid + 256 * i;
-      const int ii = idx < 32 * (D / 8) ? idx : 0;            // a K tile is one contiguous run of 32 * D halves per plane
-      pf_kh[i] = *reinterpret_cast<const uint4*>(gKh + 8 * ii);
-      pf_kl[i] = *reinterpret_cast<const uint4*>(gKl + 8 * ii);
+    for (int j = 0; j < (KT / 512 + 3) / 4; ++j) {
+      const int pc = wave + 4 * j;
+      if (pc < KT / 512)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src + pc * 512 + lane * 8), (lds_void*)(dst + pc * 512), 16, 0, 0);
     }
   };
-  auto prefetch_v = [&](int k0) {
-    const _Float16* gVh = p.vp + (long)blockIdx.y * 2 * DV * p.Nkp + k0;
-    const _Float16* gVl = gVh + (long)DV * p.Nkp;
+  auto dma_v = [&](int tile, _Float16* dst) {
+    const _Float16* src = gV + (long)tile * VT;
 #pragma unroll
-    for (int i = 0; i < PFV; ++i) {
-      const int idx = tid + 256 * i;
-      const int ii = idx < DV * 4 ? idx : 0;
-      const int d = ii >> 2, c = ii & 3;
-      pf_vh[i] = *reinterpret_cast<const uint4*>(gVh + (long)d * p.Nkp + 8 * c);
-      pf_vl[i] = *reinterpret_cast<const uint4*>(gVl + (long)d * p.Nkp + 8 * c);
-    }
-  };
-  auto stage_k = [&](_Float16* bK) {
-#pragma unroll
-    for (int i = 0; i < PFK; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < 32 * (D / 8)) {
-        const int row = idx / (D / 8), c = idx - row * (D / 8);
-        *reinterpret_cast<uint4*>(&bK[row * KP + 8 * c]) = pf_kh[i];
-        *reinterpret_cast<uint4*>(&bK[32 * KP + row * KP + 8 * c]) = pf_kl[i];
-      }
-    }
-  };
-  auto stage_v = [&](_Float16* bV) {
-#pragma unroll
-    for (int i = 0; i < PFV; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < DV * 4) {
-        const int d = idx >> 2, c = idx & 3;
-        *reinterpret_cast<uint2*>(&bV[d * VP + 8 * c]) = make_uint2(pf_vh[i].x, pf_vh[i].y);
-        *reinterpret_cast<uint2*>(&bV[d * VP + 8 * c + 4]) = make_uint2(pf_vh[i].z, pf_vh[i].w);
-        *reinterpret_cast<uint2*>(&bV[DV * VP + d * VP + 8 * c]) = make_uint2(pf_vl[i].x, pf_vl[i].y);
-        *reinterpret_cast<uint2*>(&bV[DV * VP + d * VP + 8 * c + 4]) = make_uint2(pf_vl[i].z, pf_vl[i].w);
-      }
+    for (int j = 0; j < (VT / 512 + 3) / 4; ++j) {
+      const int pc = wave + 4 * j;
+      if (pc < VT / 512)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src + pc * 512 + lane * 8), (lds_void*)(dst + pc * 512), 16, 0, 0);
     }
   };
 
@@ -663,14 +652,12 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
   const int nt = (kend - kbeg + 31) >> 5;
   _Float16* const Kb = smem;
   _Float16* const Vb = smem + 2 * KT;
-  // prologue: K(0), V(0), K(1) staged; K(2) and V(1) on their way in the prefetch registers
-  prefetch_k(kbeg);
-  prefetch_v(kbeg);
-  stage_k(Kb);
-  stage_v(Vb);
-  if (nt > 1) { prefetch_k(kbeg + 32); stage_k(Kb + KT); }
-  if (nt > 2) prefetch_k(kbeg + 64);
-  if (nt > 1) prefetch_v(kbeg + 32);
+  const int t0 = kbeg >> 5;
+  // prologue: K(0), V(0), K(1) staged
+  dma_k(t0, Kb);
+  dma_v(t0, Vb);
+  if (nt > 1) dma_k(t0 + 1, Kb + KT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const float sscale = p.scale * (1.4426950408889634f / (QSC * KSC));
@@ -735,6 +722,7 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
   };
 
   region_s(sc, Kb, [](int) {});
+  __syncthreads();            // every wave is done with K(0): iteration 0 overwrites its buffer with K(2)
   for (int t = 0; t < nt; ++t) {
     const int k0 = kbeg + 32 * t;
     // ---- S of tile t+1 with the softmax of tile t behind its triples
@@ -753,7 +741,11 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[u][r] *= alpha;
     }
-    // ---- PV of tile t with the staging of K(t+2), V(t+1) and the next prefetch behind its triples
+    // K(t+2) -> the buffer of K(t) (consumed by S(t) in iteration t-1), V(t+1) -> the buffer of V(t-1): issued here, waited
+    // for at the end of this iteration, first read in iteration t+1
+    if (t + 2 < nt) dma_k(t0 + t + 2, Kb + (t & 1) * KT);
+    if (t + 1 < nt) dma_v(t0 + t + 1, Vb + ((t + 1) & 1) * VT);
+    // ---- PV of tile t
     {
       const _Float16* Vh = Vb + (t & 1) * VT;
       const _Float16* Vl = Vh + DV * VP;
@@ -777,15 +769,11 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
           acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s2], acc[u], 0, 0, 0);
         }
         acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s2], acc[u], 0, 0, 0);
-        constexpr int LT = 2 * NT - 1;                                          // (DV = 32 has only two triples)
-        if (tr == 0 && t + 2 < nt) stage_k(Kb + (t & 1) * KT);                 // K(t) was consumed in iteration t-1
-        if (tr == (LT < 1 ? LT : 1) && t + 1 < nt) stage_v(Vb + ((t + 1) & 1) * VT);   // V(t-1) too
-        if (tr == (LT < 2 ? LT : 2) && t + 3 < nt) prefetch_k(k0 + 96);
-        if (tr == (LT < 3 ? LT : 3) && t + 2 < nt) prefetch_v(k0 + 64);
         vh = vh1; vl = vl1; vh1 = nh; vl1 = nl;
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of K(t+2), V(t+1) have landed
     __syncthreads();          // tile t consumed by every wave; K(t+2), V(t+1) visible
     sc = scn;
   }
@@ -1055,8 +1043,12 @@ static int attn_ksplit(const MspiAttnDesc* d) {
   return split < 2 ? 1 : split;
 }
 
+// plane bytes: the larger of the plain layout and the per-tile image layout (attn_pipe_kernel; AttnImg<D, DV>)
 static size_t attn_planes_bytes(const MspiAttnDesc* d) {
-  const size_t b = (size_t)d->B * d->Hh * 2 * attn_nkp(d) * (size_t)(d->D + d->Dv) * sizeof(_Float16);
+  const size_t plain = (size_t)d->B * d->Hh * 2 * attn_nkp(d) * (size_t)(d->D + d->Dv) * sizeof(_Float16);
+  const size_t kti = 2 * 32 * (size_t)(d->D + 8), vti = (2 * (size_t)d->Dv * 36 * 2 + 1023) / 1024 * 512;
+  const size_t img = (size_t)d->B * d->Hh * (attn_nkp(d) / 32) * (kti + vti) * sizeof(_Float16);
+  const size_t b = plain > img ? plain : img;
   return (b + 15) & ~(size_t)15;
 }
 
@@ -1114,6 +1106,7 @@ static int attn_fwd_impl(const MspiAttnDesc* d, const float* q, const float* k, 
     a.Nkp = (int)attn_nkp(d);
     a.kp = reinterpret_cast<_Float16*>(ws);
     a.vp = a.kp + (size_t)d->B * d->Hh * 2 * a.Nkp * d->D;
+    const size_t img_k = (size_t)d->B * d->Hh * (a.Nkp / 32) * 2 * 32 * (size_t)(d->D + 8);   // halves of all K images
     dim3 pgrid((unsigned)(a.Nkp / 32), (unsigned)(d->B * d->Hh));
     // next tile's planes fetched into registers under the current tile's MFMAs: same-box A/B on the MViTv2-S shapes 2.377 ->
     // 2.244 ms per forward, better or equal on every shape.  MSPI_ATTN_PF=0 switches it off for an A/B.
@@ -1131,8 +1124,15 @@ static int attn_fwd_impl(const MspiAttnDesc* d, const float* q, const float* k, 
     const dim3 mgrid((unsigned)(((long)d->B * d->Hh * d->Nq * (d->Dv / 4) + 255) / 256));
 #define MSPI_ATTN_PL(DD, DVV)                                                                        \
   case DD * 1000 + DVV:                                                                              \
+    if (pipe) {                                                                                      \
+      a.vp = a.kp + img_k;                                                                           \
+      hipLaunchKernelGGL((attn_kv_planes_kernel<DD, DVV, true>), pgrid, dim3(256), 0, s, a);         \
+      hipLaunchKernelGGL((attn_pipe_kernel<DD, DVV>), grid, dim3(256), 0, s, a);                     \
+      if (split > 1) hipLaunchKernelGGL((attn_merge_kernel<DVV>), mgrid, dim3(256), 0, s, a, split); \
+      break;                                                                                         \
+    }                                                                                                \
     hipLaunchKernelGGL((attn_kv_planes_kernel<DD, DVV>), pgrid, dim3(256), 0, s, a);                 \
-    if (pipe) hipLaunchKernelGGL((attn_pipe_kernel<DD, DVV>), grid, dim3(256), 0, s, a);            \
+    if (false) hipLaunchKernelGGL((attn_pipe_kernel<DD, DVV>), grid, dim3(256), 0, s, a);           \
     else if (pf) hipLaunchKernelGGL((attn_f16x3_kernel<DD, DVV, true, true>), grid, dim3(256), 0, s, a);  \
     else hipLaunchKernelGGL((attn_f16x3_kernel<DD, DVV, true, false>), grid, dim3(256), 0, s, a);    \
     if (split > 1) hipLaunchKernelGGL((attn_merge_kernel<DVV>), mgrid, dim3(256), 0, s, a, split);   \
