@@ -688,7 +688,10 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
   };
   // slice i of the online softmax over this tile's 32 keys (16 in my registers, 16 in lane^32's): 0 scale (+ mask of the keys
   // past the end), 1 running maximum and rescale factor, 2..17 one probability each (exp2, sum, split), 18 the sum
-  constexpr int NPC = 19;
+  // Slices 0 .. NP1-1 (the probabilities of the first 16-key half included) run behind the S triples; the second half's
+  // run behind the first NT PV triples, which only need the first half's probabilities -- the S region is VALU-bound
+  // (~1050 cycles of softmax against 768 of MFMA at D = 128), the PV region has no other VALU work.
+  constexpr int NPC = 19, NP1 = 10;
   auto sm_piece = [&](int i, int k0) {
     if (i == 0) {
 #pragma unroll
@@ -729,11 +732,11 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
     if (t + 1 < nt) {
       region_s(scn, Kb + ((t + 1) & 1) * KT, [&](int st) {
 #pragma unroll
-        for (int i = st * NPC / NS; i < (st + 1) * NPC / NS; ++i) sm_piece(i, k0);
+        for (int i = st * NP1 / NS; i < (st + 1) * NP1 / NS; ++i) sm_piece(i, k0);
       });
     } else {
 #pragma unroll
-      for (int i = 0; i < NPC; ++i) sm_piece(i, k0);
+      for (int i = 0; i < NP1; ++i) sm_piece(i, k0);
     }
     if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {      // no row of this wave raised its maximum: nothing to rescale
 #pragma unroll
@@ -743,8 +746,6 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
     }
     // K(t+2) -> the buffer of K(t) (consumed by S(t) in iteration t-1), V(t+1) -> the buffer of V(t-1): issued here, waited
     // for at the end of this iteration, first read in iteration t+1
-    if (t + 2 < nt) dma_k(t0 + t + 2, Kb + (t & 1) * KT);
-    if (t + 1 < nt) dma_v(t0 + t + 1, Vb + ((t + 1) & 1) * VT);
     // ---- PV of tile t
     {
       const _Float16* Vh = Vb + (t & 1) * VT;
@@ -769,6 +770,12 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
           acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s2], acc[u], 0, 0, 0);
         }
         acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s2], acc[u], 0, 0, 0);
+        if (tr < NT) {
+#pragma unroll
+          for (int i = NP1 + tr * (NPC - NP1) / NT; i < NP1 + (tr + 1) * (NPC - NP1) / NT; ++i) sm_piece(i, k0);
+        }
+        if (tr == 0 && t + 2 < nt) dma_k(t0 + t + 2, Kb + (t & 1) * KT);
+        if (tr == (2 * NT > 1 ? 1 : 0) && t + 1 < nt) dma_v(t0 + t + 1, Vb + ((t + 1) & 1) * VT);
         vh = vh1; vl = vl1; vh1 = nh; vl1 = nl;
         __builtin_amdgcn_sched_barrier(0);
       }
