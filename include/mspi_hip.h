@@ -192,6 +192,8 @@ int mspi_attn_fwd(const MspiAttnDesc* d, const float* q, const float* k, const f
 /* The same attention (f16x3 only) with K and V split ONCE per (sequence, head) into f16 hi/lo planes in a caller-owned
  * workspace of mspi_attn_ws_bytes(d) bytes, instead of by every query tile of that head on its own copy: two launches (plane
  * kernel, attention kernel), results bit-identical to mspi_attn_fwd.  mspi_attn_ws_bytes returns 0 for other precisions.
+ * Without bias, mask and token index the attention kernel is the software-pipelined form (csrc/attn.hip, attn_pipe_kernel:
+ * the planes are then per-tile LDS images staged by LDS-DMA); same products in the same order, same results.
  * Few-query shapes (fewer than 256 query tiles over all heads, at least 24 key tiles; no bias, mask or token index) are
  * additionally split along the keys: up to 8 workgroups per query tile each walk a slice of the key tiles and a third
  * launch merges their (O, running max, running sum) in fixed order -- deterministic, equal to the one-pass result up to
