@@ -98,6 +98,14 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
   lo = (_Float16)(x - (float)hi);
 }
 
+// Pre-split activation planes are BLOCKED: 16 rows x 32 k halves = 1 KB contiguous per block, blocks k-fastest, so that the
+// k32 stage of a 16-row group is ONE contiguous 1-KB LDS-DMA piece of 8 full cache lines (row-major [M][K] planes hand the
+// loader 16 half-lines per piece: 30 instead of 43 B/clk/CU of fill, tools/dma_issue_probe.hip).  kt = K / 32; rows are
+// allocated up to a multiple of 16.
+__device__ __forceinline__ long plane_off(long m, int k, int kt) {
+  return ((m >> 4) * kt + (k >> 5)) * 512 + (m & 15) * 32 + (k & 31);
+}
+
 __device__ __forceinline__ bool nonfinite(float v) { return !(fabsf(v) <= 3.4028235e38f); }
 __device__ __forceinline__ void report_nonfinite(int* status, bool bad) {
   if (bad && status) *reinterpret_cast<volatile int*>(status) = 1;   // idempotent: racing stores write the same value

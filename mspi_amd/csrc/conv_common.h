@@ -41,7 +41,7 @@ struct ConvArgs {
   int dbg;          // ablation switches for tools/gemm_probe.py (MSPI_CONV_DBG); 0 in production
   int ksplit;       // split-K: gridDim.y workgroups share an output tile, each owns a contiguous range of K steps ...
   float* ws;        // ... and writes its partial sums to ws[z][M][Cout] (no bias / residual / activation); NULL: no split
-  // pre-split activations (conv_gemm_dma_kernel<..., APRE>): A is two f16 planes [2][M][ldxs] (hi, then lo `xplane` elements
+  // pre-split activations (conv_gemm_dma_kernel<..., APRE>): A is two BLOCKED f16 planes (common.h plane_off; ldxs == K) (hi, then lo `xplane` elements
   // later), written by a producer's epilogue; the kernel then DMAs them like the weight planes and splits nothing
   const _Float16* xs;
   long ldxs, xplane;

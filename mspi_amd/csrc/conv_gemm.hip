@@ -587,16 +587,17 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   v4h h, l;
 #pragma unroll
   for (int e = 0; e < 4; ++e) { _Float16 hh, ll; split_f16(a[e], hh, ll); h[e] = hh; l[e] = ll; }
-  *reinterpret_cast<v4h*>(out + m * ldo + c) = h;
-  *reinterpret_cast<v4h*>(out + plane + m * ldo + c) = l;
+  const long o = plane_off(m, c, K4 >> 3);
+  *reinterpret_cast<v4h*>(out + o) = h;
+  *reinterpret_cast<v4h*>(out + plane + o) = l;
 }
 }  // namespace mspi
 
 extern "C" int mspi_split_planes_fwd(const float* x, int64_t ldx, int64_t M, int32_t K, void* planes, int64_t ldo, int64_t plane,
                                      mspi_stream_t stream) {
-  MSPI_REQUIRE(x && planes && M > 0 && K > 0 && (K & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0 && ldo >= K && plane >= M * ldo &&
+  MSPI_REQUIRE(x && planes && M > 0 && K > 0 && (K & 31) == 0 && (ldx & 3) == 0 && ldo == K && plane >= (M + 15) / 16 * 16 * ldo &&
                    aligned16(x) && aligned16(planes) && (plane & 7) == 0,
-               "mspi_split_planes_fwd: K / ldx / ldo multiples of 4, 16-B aligned pointers, plane >= M*ldo");
+               "mspi_split_planes_fwd: K a multiple of 32, ldo == K (blocked planes), 16-B aligned pointers, plane >= roundup16(M)*K");
   const long total = M * (K / 4);
   MSPI_REQUIRE((total + 255) / 256 < (1L << 31), "mspi_split_planes_fwd: grid too large");
   hipLaunchKernelGGL(mspi::split_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
@@ -612,8 +613,9 @@ __global__ __launch_bounds__(256) void join_planes_kernel(const _Float16* __rest
   if (idx >= M * K4) return;
   const long m = idx / K4;
   const int c = (int)(idx - m * K4) * 4;
-  const v4h h = *reinterpret_cast<const v4h*>(in + m * ldi + c);
-  const v4h l = *reinterpret_cast<const v4h*>(in + plane + m * ldi + c);
+  const long o = plane_off(m, c, K4 >> 3);
+  const v4h h = *reinterpret_cast<const v4h*>(in + o);
+  const v4h l = *reinterpret_cast<const v4h*>(in + plane + o);
   float4 v;
   v.x = (float)h[0] + (float)l[0]; v.y = (float)h[1] + (float)l[1]; v.z = (float)h[2] + (float)l[2]; v.w = (float)h[3] + (float)l[3];
   *reinterpret_cast<float4*>(y + m * ldy + c) = v;
@@ -622,9 +624,9 @@ __global__ __launch_bounds__(256) void join_planes_kernel(const _Float16* __rest
 
 extern "C" int mspi_join_planes_fwd(const void* planes, int64_t ldi, int64_t plane, int64_t M, int32_t K, float* y, int64_t ldy,
                                     mspi_stream_t stream) {
-  MSPI_REQUIRE(planes && y && M > 0 && K > 0 && (K & 3) == 0 && (ldi & 3) == 0 && (ldy & 3) == 0 && ldi >= K && ldy >= K &&
-                   plane >= M * ldi && aligned16(planes) && aligned16(y) && (plane & 7) == 0,
-               "mspi_join_planes_fwd: K / ldi / ldy multiples of 4, 16-B aligned pointers, plane >= M*ldi");
+  MSPI_REQUIRE(planes && y && M > 0 && K > 0 && (K & 31) == 0 && ldi == K && (ldy & 3) == 0 && ldy >= K &&
+                   plane >= (M + 15) / 16 * 16 * ldi && aligned16(planes) && aligned16(y) && (plane & 7) == 0,
+               "mspi_join_planes_fwd: K a multiple of 32, ldi == K (blocked planes), 16-B aligned pointers, plane >= roundup16(M)*K");
   const long total = M * (K / 4);
   MSPI_REQUIRE((total + 255) / 256 < (1L << 31), "mspi_join_planes_fwd: grid too large");
   hipLaunchKernelGGL(mspi::join_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -640,12 +642,13 @@ extern "C" int mspi_gemm_sp_fwd(const MspiConvDesc* d, const void* x_planes, int
                    d->padH == 0 && d->padW == 0, "mspi_gemm_sp_fwd: a plain GEMM on rows (1x1x1, stride 1, no padding)");
   MSPI_REQUIRE(d->prec == PREC_F16X3 && d->w_scale > 0.f && d->C > 0 && (d->C % BK) == 0 && d->ldw == d->C,
                "mspi_gemm_sp_fwd: f16x3 weights, K a multiple of 32 with ldw == K");
-  MSPI_REQUIRE((ldx & 7) == 0 && ldx >= d->C && (xplane & 7) == 0 && aligned16(x_planes) && aligned16(w),
-               "mspi_gemm_sp_fwd: plane rows must be 16-B aligned");
+  MSPI_REQUIRE(ldx == d->C && (xplane & 7) == 0 && aligned16(x_planes) && aligned16(w),
+               "mspi_gemm_sp_fwd: blocked input planes have ldx == K");
   const long Ml = (long)d->N * d->T * d->H * d->W;
-  MSPI_REQUIRE(Ml > 0 && Ml < (1L << 31) && xplane >= Ml * ldx, "mspi_gemm_sp_fwd: bad extent");
-  MSPI_REQUIRE(!y_planes || (ldys >= d->Cout && yplane >= Ml * ldys && (d->Cout % 32) == 0 && (ldys & 1) == 0 && (yplane & 1) == 0 &&
-                              aligned16(y_planes)), "mspi_gemm_sp_fwd: output planes need Cout %% 32 == 0 and even strides");
+  const long Mp = (Ml + 15) / 16 * 16;
+  MSPI_REQUIRE(Ml > 0 && Ml < (1L << 31) && xplane >= Mp * ldx, "mspi_gemm_sp_fwd: bad extent (plane >= roundup16(M) * K)");
+  MSPI_REQUIRE(!y_planes || (ldys == d->Cout && yplane >= Mp * ldys && (d->Cout % 32) == 0 && (yplane & 7) == 0 &&
+                              aligned16(y_planes)), "mspi_gemm_sp_fwd: blocked output planes need Cout %% 32 == 0, ldys == Cout, plane >= roundup16(M) * Cout");
   MSPI_REQUIRE(!y || d->ldy >= d->Cout, "mspi_gemm_sp_fwd: ldy < Cout");
   MSPI_REQUIRE(!res || d->ldr >= d->Cout, "mspi_gemm_sp_fwd: ldr < Cout");
   ConvArgs a;

@@ -100,9 +100,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int q = i * NW + wave;
-        const int m = m0 + q * 16 + (lane >> 2);
-        const bool ok = m < p.M;
-        const _Float16* src = p.xs + (long)(ok ? m : 0) * p.ldxs + k0 + b_seg * 8;
+        const bool ok = m0 + q * 16 < p.M;       // blocked planes: the whole 16-row group exists (rows are allocated to a multiple of 16)
+        const _Float16* src = p.xs + ((long)((m0 >> 4) + (ok ? q : 0)) * (p.ldxs >> 5) + (k0 >> 5)) * 512 + (lane >> 2) * 32 + b_seg * 8;
         const void* s_hi = ok ? (const void*)src : (const void*)g_zero16;
         const void* s_lo = ok ? (const void*)(src + p.xplane) : (const void*)g_zero16;
         __builtin_amdgcn_global_load_lds(s_hi, (lds_void*)(base + q * 1024), 16, 0, 0);
@@ -351,8 +350,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
         const int c0 = col & ~1;
         if (row < p.M) {      // Cout is a multiple of 32 for plane outputs (checked on the host): both columns exist
           h2 hi = {a[0], b[0]}, lo = {a[1], b[1]};
-          *reinterpret_cast<h2*>(p.ys + (long)row * p.ldys + c0) = hi;
-          *reinterpret_cast<h2*>(p.ys + p.yplane + (long)row * p.ldys + c0) = lo;
+          const long po = plane_off(row, c0, (int)(p.ldys >> 5));
+          *reinterpret_cast<h2*>(p.ys + po) = hi;
+          *reinterpret_cast<h2*>(p.ys + p.yplane + po) = lo;
         }
       }
       continue;

@@ -75,8 +75,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         h4 h, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { _Float16 hh, ll; split_f16(a[e], hh, ll); h[e] = hh; l[e] = ll; }
-        *reinterpret_cast<h4*>(ys + row * ldys + i * 4) = h;
-        *reinterpret_cast<h4*>(ys + yplane + row * ldys + i * 4) = l;
+        const long po = plane_off(row, i * 4, C >> 5);      // blocked planes (common.h)
+        *reinterpret_cast<h4*>(ys + po) = h;
+        *reinterpret_cast<h4*>(ys + yplane + po) = l;
       } else {
         *reinterpret_cast<float4*>(yr + i * 4) = o;
       }
@@ -349,8 +350,8 @@ static int layernorm_impl(const float* x, int64_t ldx, int64_t sNx, float* y, in
   MSPI_REQUIRE(N > 0 && R > 0 && C > 0 && (C & 3) == 0 && C <= LN_MAXC, "%s: C=%d must be a multiple of 4, <= %d", who, C, LN_MAXC);
   MSPI_REQUIRE((ldx & 3) == 0 && ldx >= C && (sNx & 3) == 0, "%s: bad input row/sample stride", who);
   MSPI_REQUIRE(planes || ((ldy & 3) == 0 && ldy >= C && (sNy & 3) == 0 && aligned16(y)), "%s: bad output row/sample stride", who);
-  MSPI_REQUIRE(!planes || ((ldo & 7) == 0 && ldo >= C && plane >= M * ldo && (plane & 7) == 0 && aligned16(planes)),
-               "%s: output planes need 16-B aligned rows and plane >= M*ld", who);
+  MSPI_REQUIRE(!planes || ((C & 31) == 0 && ldo == C && plane >= (M + 15) / 16 * 16 * ldo && (plane & 7) == 0 && aligned16(planes)),
+               "%s: blocked output planes need C %% 32 == 0, ld == C and plane >= roundup16(M)*C", who);
   MSPI_REQUIRE(aligned16(x) && aligned16(gamma) && aligned16(beta) && (!table || aligned16(table)), "%s: pointers must be 16-B aligned", who);
   MSPI_REQUIRE(M < (1L << 31), "%s: too many rows", who);
   const int nv = C / 4;

@@ -259,8 +259,9 @@ SP_ENABLED = _os.environ.get("MSPI_PRESPLIT", "1") != "0"   # A/B switch: pre-sp
 
 
 class SP:
-    """Pre-split activation rows: two f16 planes [2][M][ld] (hi, lo) in one buffer -- what a producer's epilogue hands to
-    the f16x3 GEMM so that neither operand needs conversion work in the loop (include/mspi_hip.h, mspi_gemm_sp_fwd).
+    """Pre-split activation rows: two f16 planes (hi, lo) in one buffer -- what a producer's epilogue hands to the f16x3 GEMM so
+    that neither operand needs conversion work in the loop (include/mspi_hip.h, mspi_gemm_sp_fwd).  Each plane is BLOCKED:
+    16 rows x 32 columns = 1 KB contiguous per block, blocks column-fastest, rows allocated to a multiple of 16 (ld == C).
     Same logical shape as a dense CL; only GEMM-shaped consumers (conv on 1x1x1 / Linear packs) accept it."""
     __slots__ = ("buf", "N", "T", "H", "W", "C", "ld")
 
@@ -273,7 +274,7 @@ class SP:
 
     @property
     def plane(self):
-        return self.M * self.ld
+        return (self.M + 15) // 16 * 16 * self.ld      # blocked planes: rows allocated to a multiple of 16
 
     @property
     def ptr(self):
@@ -287,7 +288,12 @@ def sp_supported(c):
 
 def alloc_sp(N, T, H, W, Cc, device):
     assert Cc % 32 == 0
-    return SP(torch.empty(2 * N * T * H * W * Cc, dtype=torch.float16, device=device), N, T, H, W, Cc, Cc)
+    m = N * T * H * W
+    mp = (m + 15) // 16 * 16
+    buf = torch.empty(2 * mp * Cc, dtype=torch.float16, device=device)
+    if mp != m:      # the rows that pad the last 16-row group are read by the GEMM (their outputs are never stored) and by the range check
+        buf.view(2, mp * Cc)[:, (mp - 16) * Cc:].zero_()
+    return SP(buf, N, T, H, W, Cc, Cc)
 
 
 def join_planes(sp):
@@ -693,7 +699,7 @@ def conv(x, pk, out=None, res=None, gate=None, act=None, tile=None, sp_out=False
     if isinstance(x, SP):
         if tuning:   # planes: the hi plane carries the magnitude (an out-of-range layer is fixed from the NEXT forward on: its
             #          producer stops emitting planes once this pack is fp32)
-            _range_check(pk, lambda: x.buf[: x.M * x.ld].view(x.M, x.ld)[:, : x.C].abs().max(), "planes -> %dx%d" % (pk.cin, pk.cout))
+            _range_check(pk, lambda: x.buf[: x.plane].abs().max(), "planes -> %dx%d" % (pk.cin, pk.cout))      # the hi plane (pad rows are zero)
         if pk.prec == PREC_F16X3:
             return _conv_sp(x, pk, out, res, act, tile, sp_out)
         # The range check has moved this layer to the fp32 path while its producer had already emitted planes (from the next

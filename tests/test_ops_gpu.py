@@ -566,8 +566,12 @@ def test_presplit_ln_gemm_gemm_chain(dev, M, C, Hd):
             assert (y.buf - plain.buf).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
     # planes reproduce the fp32 value to 22 bits
     sp = E.layernorm(xcl, *ln, 1e-6, sp=True)
-    rec = sp.buf[: M * C].float() + sp.buf[M * C:].float()
+    rec = E.join_planes(sp).as_rows()[:, :C].reshape(-1)      # planes are blocked (16 x 32 tiles): read them back through the ABI
     want = F.layer_norm(x, (C,), gam, bet, 1e-6).reshape(-1)
+    mp = (M + 15) // 16 * 16
+    hi = sp.buf[: mp * C].view(mp // 16, C // 32, 16, 32).permute(0, 2, 1, 3).reshape(mp, C)[:M].float()
+    lo = sp.buf[mp * C:].view(mp // 16, C // 32, 16, 32).permute(0, 2, 1, 3).reshape(mp, C)[:M].float()
+    assert torch.equal((hi + lo).reshape(-1), rec), "blocked layout: element (m, k) of a plane at ((m/16)(K/32) + k/32) 512 + (m%16) 32 + k%32"
     assert (rec.cpu() - want).abs().max().item() < 3e-6 * want.abs().max().item() + 1e-6
     with pytest.raises(MspiError, match="split-plane"):
         E.conv(xcl, p1, sp_out=True)

@@ -5,6 +5,7 @@
 //  mode 3: 4 waves, each MFMA followed by R independent VALU FMAs in program order (same wave)
 //  mode 4: 8 waves, all run mode 3's interleaved stream
 //  mode 5: mode 2 with v_exp_f32 (transcendental) instead of FMA in the VALU waves
+//  mode 6 / 7: mode 2 with s_setprio 3 on the MFMA waves / on the VALU waves
 // One workgroup on one CU; times by s_memtime (shader clock).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -21,8 +22,10 @@ __global__ __launch_bounds__(512, 1) void k(float* out, unsigned long long* cyc,
   float f[8];
   for (int e = 0; e < 8; ++e) f[e] = 0.001f * (lane + e);
   const float c0 = 1.0001f, c1 = 0.0001f;
-  const bool mf = (MODE == 0) || (MODE == 2 && wave < 4) || (MODE == 5 && wave < 4) || MODE == 3 || MODE == 4;
-  const bool va = (MODE == 1) || (MODE == 2 && wave >= 4) || (MODE == 5 && wave >= 4) || MODE == 3 || MODE == 4;
+  const bool mf = (MODE == 0) || ((MODE == 2 || MODE == 6 || MODE == 7) && wave < 4) || (MODE == 5 && wave < 4) || MODE == 3 || MODE == 4;
+  const bool va = (MODE == 1) || ((MODE == 2 || MODE == 6 || MODE == 7) && wave >= 4) || (MODE == 5 && wave >= 4) || MODE == 3 || MODE == 4;
+  if (MODE == 6 && mf) __builtin_amdgcn_s_setprio(3);      // mode 6: mode 2 with the MFMA waves at priority 3
+  if (MODE == 7 && va) __builtin_amdgcn_s_setprio(3);      // mode 7: mode 2 with the VALU waves at priority 3
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; it += 16) {
@@ -73,6 +76,9 @@ int main() {
   run<4, 16>("8 waves: all MFMA + 16 FMA interleaved", out, cyc, 8);
   run<1, 4>("4 waves, 4 FMA per iteration", out, cyc, 4);
   run<3, 4>("4 waves: MFMA + 4 FMA interleaved in one wave", out, cyc, 4);
+  run<6, 8>("8 waves: 0-3 MFMA at s_setprio 3, 4-7 8 FMA", out, cyc, 8);
+  run<7, 8>("8 waves: 0-3 MFMA, 4-7 8 FMA at s_setprio 3", out, cyc, 8);
+  run<6, 16>("8 waves: 0-3 MFMA at s_setprio 3, 4-7 16 FMA", out, cyc, 8);
   run<5, 4>("8 waves: 0-3 MFMA, 4-7 4 v_exp_f32", out, cyc, 8);
   run<5, 8>("8 waves: 0-3 MFMA, 4-7 8 v_exp_f32", out, cyc, 8);
   return 0;
