@@ -416,12 +416,21 @@ int mspi_resize_norm_fwd(const unsigned char* rgb, int32_t Hin, int32_t Win, uns
                          const float* std3_host, mspi_stream_t stream);
 
 /* Pre-split activations.  The f16x3 GEMM computes x*w from f16 hi/lo halves of both operands; the weights are split at pack
- * time, and a producer may hand the activations over ALREADY split: two f16 planes [2][M][ld] (hi plane, lo plane `plane`
- * elements later; hi = f16(x), lo = f16(x - hi) -- the same split the kernels otherwise do in registers, so results are
- * bit-identical).  mspi_gemm_sp_fwd is the dense (1x1x1 / nn.Linear) GEMM on such planes: both operands then go
- * HBM -> LDS -> MFMA with no conversion work in the loop.  d: as for mspi_conv_fwd with C % 32 == 0, ldw == C, prec f16x3;
+ * time, and a producer may hand the activations over ALREADY split: two f16 planes (hi plane, lo plane `plane` elements
+ * later; hi = f16(x), lo = f16(x - hi) -- the same split the kernels otherwise do in registers, so results are
+ * bit-identical).  Each plane is BLOCKED: K % 32 == 0, the row count is padded to a multiple of 16, and element (m, k) sits at
+ *     ((m / 16) * (K / 32) + k / 32) * 512 + (m % 16) * 32 + k % 32        (halves)
+ * i.e. a 16-row x 32-column block is 1 KB contiguous and the blocks of a row group follow each other along k: the k32 stage
+ * of a 16-row group is one contiguous 1-KB LDS-DMA piece of 8 full cache lines (row-major planes hand the loader 16 half
+ * lines per piece: 30 instead of 43 B/clk/CU of fill, tools/dma_issue_probe.hip).  `ld` arguments of planes must equal K;
+ * `plane` >= roundup16(M) * K; the pad rows are read (never stored): keep them finite.
+ * mspi_gemm_sp_fwd is the dense (1x1x1 / nn.Linear) GEMM on such planes: both operands go HBM -> LDS -> MFMA with no
+ * conversion work in the loop.  d: as for mspi_conv_fwd with C % 32 == 0, ldw == C, prec f16x3; `w`: the f16 hi/lo weight
+ * planes of mspi_conv_fwd BLOCKED the same way (rows = output channels, zero-padded to a multiple of 16; lo plane
+ * roundup16(Cout) * K halves after the hi plane; engine.sp_weights builds it);
  * d->tile: -1 heuristic, 6/7/9/10/11 = 128 x {128,64,96,192,256}, 12/13/14 = 256 x {256,192,128}.  The result goes to y
- * (fp32 rows, ldy) or, when y_planes != NULL, to output planes (for the next GEMM).  mspi_split_planes_fwd converts fp32 rows. */
+ * (fp32 rows, ldy) or, when y_planes != NULL, to blocked output planes (ldys == Cout, Cout % 32 == 0) for the next GEMM.
+ * mspi_split_planes_fwd converts fp32 rows. */
 int mspi_layernorm_sp_fwd(const float* x, int64_t ldx, int64_t sample_stride_x, void* planes, int64_t ldo, int64_t plane,
                           const float* gamma, const float* beta, float eps, int32_t N, int32_t R, int32_t C, int32_t act,
                           mspi_stream_t stream);   /* mspi_layernorm_fwd writing pre-split planes (rows dense, n*R + r) */

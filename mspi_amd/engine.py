@@ -324,7 +324,7 @@ def fold_bn(weight, bias, bn):
 
 class PackedConv:
     __slots__ = ("w", "bias", "k", "stride", "pad", "cin", "cin_s", "cout", "cout_s", "ldw", "act", "prec", "w_scale", "thin",
-                 "w32", "ldw32", "checked")
+                 "w32", "ldw32", "checked", "wsp")
 
 
 def pack_conv(weight, bias=None, bn=None, stride=(1, 1, 1), pad=(0, 0, 0), act=ACT_NONE, cin_stored=None,
@@ -353,6 +353,7 @@ def pack_conv(weight, bias=None, bn=None, stride=(1, 1, 1), pad=(0, 0, 0), act=A
     wf[:, :K] = wp.reshape(cout_s, K)
     p = PackedConv()
     p.thin = None
+    p.wsp = None
     p.checked = False
     dev = w.device if device is None else device
     p.prec, p.w_scale = prec, 1.0
@@ -633,6 +634,18 @@ def _out_extent(T, H, W, k, s, p):
 SP_TILES = (6, 7, 9, 10, 11, 12, 13, 14)
 
 
+def sp_weights(pk):
+    """The weights of an f16x3 pack in the form mspi_gemm_sp_fwd takes: blocked like the activation planes (16 rows x 32 k =
+    1 KB contiguous, k-fastest, rows zero-padded to a multiple of 16), so that every LDS-DMA piece of a stage is 8 full cache
+    lines.  Built on first use, kept on the pack."""
+    if pk.wsp is None:
+        npad = (pk.cout_s + 15) // 16 * 16
+        w = torch.zeros(2, npad, pk.ldw, dtype=torch.float16, device=pk.w.device)
+        w[:, : pk.cout_s] = pk.w
+        pk.wsp = w.view(2, npad // 16, 16, pk.ldw // 32, 32).permute(0, 1, 3, 2, 4).contiguous()
+    return pk.wsp
+
+
 def _conv_sp(x, pk, out, res, act, tile, sp_out):
     """Dense GEMM on pre-split activation planes; result as fp32 rows (CL) or, sp_out, as planes for the next GEMM."""
     lib = _lib.load()
@@ -664,7 +677,7 @@ def _conv_sp(x, pk, out, res, act, tile, sp_out):
     d.ldw, d.ldr = pk.ldw, (res.ld if res is not None else 0)
     d.act = pk.act if act is None else act
     d.prec, d.w_scale = pk.prec, pk.w_scale
-    args = (x.ptr, x.ld, x.plane, pk.w.data_ptr(), pk.bias.data_ptr() if pk.bias is not None else None,
+    args = (x.ptr, x.ld, x.plane, sp_weights(pk).data_ptr(), pk.bias.data_ptr() if pk.bias is not None else None,
             res.ptr if res is not None else None, None if sp_out else out.ptr, out.ptr if sp_out else None,
             out.ld if sp_out else 0, out.plane if sp_out else 0, _stream())
 

@@ -55,7 +55,7 @@ for M, K, N in SHAPES:
     for t in [6, 7, 9, 10, 11, 12, 13, 14]:
         d.tile = t
         def run():
-            _lib.check(lib.mspi_gemm_sp_fwd(C.byref(d), planes.data_ptr(), K, M * K, pk.w.data_ptr(), pk.bias.data_ptr(), None,
+            _lib.check(lib.mspi_gemm_sp_fwd(C.byref(d), planes.data_ptr(), K, M * K, E.sp_weights(pk).data_ptr(), pk.bias.data_ptr(), None,
                                             y.data_ptr(), None, 0, 0, torch.cuda.current_stream().cuda_stream), "gemm_sp")
         try:
             res[t] = timeit(run)
