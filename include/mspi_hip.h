@@ -97,6 +97,11 @@ typedef struct MspiConvDesc {
                                       5 256x128, 6..11 LDS-DMA kernel (128 rows, 4 waves) with 128 / 64 / all (<= 256) /
                                       96 / 192 / 32 columns per tile, 12..14 its 256-row / 8-wave form with 256 / 192 /
                                       128 columns (f16x3, 16-B gather only) */
+  const void* w_blocked;           /* optional (NULL: none), F16X3 only: the same hi/lo weight planes BLOCKED as described at
+                                      mspi_gemm_sp_fwd (16 output channels x 32 k = 1 KB contiguous per block, k-fastest,
+                                      rows zero-padded to a multiple of 16).  The LDS-DMA kernels (tile 6..14, and the
+                                      heuristic when it picks them) stage their weights from it: every piece is then 8 full
+                                      cache lines instead of 16 half lines.  The other kernels read `w`. */
 } MspiConvDesc;
 
 int mspi_conv_fwd(const MspiConvDesc* d, const float* x, const float* w, const float* bias /*[Cout] or NULL*/,

@@ -31,6 +31,7 @@ class ConvDesc(C.Structure):
         ("prec", C.c_int32),
         ("w_scale", C.c_float),
         ("tile", C.c_int32),
+        ("w_blocked", C.c_void_p),
     ]
 
 

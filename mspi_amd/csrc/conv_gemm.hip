@@ -471,7 +471,7 @@ static int conv_fwd_impl(const MspiConvDesc* d, const float* x, const float* w, 
   static const int dbg = getenv("MSPI_CONV_DBG") ? atoi(getenv("MSPI_CONV_DBG")) : 0;
   a.dbg = dbg;
   a.ws = ws; a.ksplit = ksplit;
-  a.xs = nullptr; a.ldxs = 0; a.xplane = 0; a.ys = nullptr; a.ldys = 0; a.yplane = 0;
+  a.wb = (d->prec == PREC_F16X3) ? (const _Float16*)d->w_blocked : nullptr; a.xs = nullptr; a.ldxs = 0; a.xplane = 0; a.ys = nullptr; a.ldys = 0; a.yplane = 0;
   if (ws) {
     // split-K (mspi_conv_splitk_fwd): 64x64 tiles, gridDim.y = ksplit slices of the K loop, then the ordered reduction
     MSPI_REQUIRE(!gate && (d->Cout & 3) == 0 && (d->ldy & 3) == 0 && (!res || (d->ldr & 3) == 0) && aligned16(y) && aligned16(ws) &&
@@ -662,6 +662,7 @@ extern "C" int mspi_gemm_sp_fwd(const MspiConvDesc* d, const void* x_planes, int
   a.out_scale = 1.0f / d->w_scale;
   a.status = g_status_word;
   a.dbg = 0; a.ws = nullptr; a.ksplit = 1;
+  a.wb = nullptr;      // (the pre-split form takes blocked weights through `w`)
   a.xs = (const _Float16*)x_planes; a.ldxs = ldx; a.xplane = xplane;
   a.ys = (_Float16*)y_planes; a.ldys = ldys; a.yplane = yplane;
   int bn, rows = 128;

@@ -89,8 +89,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
   }
   // ---- weight DMA assignment: plane chunks (i*4+wave)*64 + lane: row r = q/4, slot q%4, segment = slot ^ ((r>>2)&3)
   const _Float16* wh = reinterpret_cast<const _Float16*>(p.w);
-  // pre-split form: the weights come blocked like the activation planes (engine.PackedConv.wsp), rows padded to 16
-  const long wplane = APRE ? (long)((p.Cout + 15) / 16 * 16) * p.ldw : (long)p.Cout * p.ldw;
+  // blocked weights (the pre-split form always; the others when the caller supplies them): rows padded to 16
+  const bool wblk = APRE || p.wb != nullptr;
+  if (wblk && !APRE) wh = p.wb;
+  const long wplane = wblk ? (long)((p.Cout + 15) / 16 * 16) * p.ldw : (long)p.Cout * p.ldw;
   const int b_seg = (lane & 3) ^ ((lane >> 4) & 3);
 
   auto issue_stage = [&](int st, int k0) {
@@ -132,8 +134,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
       if ((i * NW + wave) * 16 < BN) {   // wave-uniform: the last group of 16 rows may not exist for this wave
         const int r = (i * NW + wave) * 16 + (lane >> 2);
         const int n = n0 + r;
-        const bool ok = APRE ? n0 + (i * NW + wave) * 16 < p.Cout : n < p.Cout;
-        const _Float16* q = APRE ? wh + ((long)((n0 >> 4) + (ok ? i * NW + wave : 0)) * (p.ldw >> 5) + (k0 >> 5)) * 512 + (lane >> 2) * 32 + b_seg * 8
+        const bool ok = wblk ? n0 + (i * NW + wave) * 16 < p.Cout : n < p.Cout;
+        const _Float16* q = wblk ? wh + ((long)((n0 >> 4) + (ok ? i * NW + wave : 0)) * (p.ldw >> 5) + (k0 >> 5)) * 512 + (lane >> 2) * 32 + b_seg * 8
                                  : wh + (long)(ok ? n : 0) * p.ldw + k0 + b_seg * 8;
         const void* s_hi = ok ? (const void*)q : (const void*)g_zero16;
         const void* s_lo = ok ? (const void*)(q + wplane) : (const void*)g_zero16;

@@ -634,6 +634,9 @@ def _out_extent(T, H, W, k, s, p):
 SP_TILES = (6, 7, 9, 10, 11, 12, 13, 14)
 
 
+W_BLOCKED = _os.environ.get("MSPI_W_BLOCKED", "1") != "0"      # A/B switch: blocked weights for the LDS-DMA kernels on fp32 activations
+
+
 def sp_weights(pk):
     """The weights of an f16x3 pack in the form mspi_gemm_sp_fwd takes: blocked like the activation planes (16 rows x 32 k =
     1 KB contiguous, k-fastest, rows zero-padded to a multiple of 16), so that every LDS-DMA piece of a stage is 8 full cache
@@ -759,6 +762,7 @@ def conv(x, pk, out=None, res=None, gate=None, act=None, tile=None, sp_out=False
     d.ldr = res.ld if res is not None else 0
     d.act = pk.act if act is None else act
     d.prec, d.w_scale = pk.prec, pk.w_scale
+    d.w_blocked = sp_weights(pk).data_ptr() if (pk.prec == PREC_F16X3 and W_BLOCKED) else None      # the LDS-DMA kernels' weight source
     if res is not None and (res.M != out.M or not res.dense):
         raise MspiError("conv: residual rows %d != output rows %d (or residual not dense)" % (res.M, out.M))
     M = N * To * Ho * Wo
