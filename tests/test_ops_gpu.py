@@ -579,6 +579,43 @@ def test_presplit_ln_gemm_gemm_chain(dev, M, C, Hd):
         E.conv(sp, E.pack_conv(torch.randn(8, C, 1, 3, 3, generator=g), None, None, (1, 1, 1), (0, 1, 1), device=dev))
 
 
+@pytest.mark.parametrize("case", [(1000, 192, 136, (1, 1, 1)), (2 * 6 * 9 * 9, 40, 72, (3, 3, 3))])
+def test_dma_gemm_blocked_weights(dev, case):
+    """MspiConvDesc.w_blocked: the LDS-DMA kernels (tile codes 6, 7, 9, 14) staging their weights from the blocked copy
+    (engine.sp_weights: 16 output channels x 32 k per 1-KB block, rows zero-padded to 16) give bit for bit what they give from
+    the row-major planes -- 1x1x1 and 3x3x3, output channels that are not a multiple of 16, ragged M."""
+    from mspi_amd import engine as E
+    from mspi_amd.module import to_cl
+    if E.DEFAULT_PREC != E.PREC_F16X3:
+        pytest.skip("f16x3 only")
+    M, Cin, Cout, k = case
+    g = torch.Generator().manual_seed(M + Cin)
+    if k == (1, 1, 1):
+        x = torch.randn(1, Cin, 1, M, 1, generator=g)
+    else:
+        x = torch.randn(2, Cin, 6, 9, 9, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) / math.sqrt(Cin * k[0] * k[1] * k[2])
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv3d(x.double(), w.double(), b.double(), 1, tuple(kk // 2 for kk in k))
+    xc = to_cl(x.to(dev))
+    pk = E.pack_conv(w, b, None, (1, 1, 1), tuple(kk // 2 for kk in k), cin_stored=xc.Cs, device=dev)
+    wb = E.sp_weights(pk)
+    npad = (pk.cout_s + 15) // 16 * 16
+    assert wb.shape == (2, npad // 16, pk.ldw // 32, 16, 32)
+    back = wb.permute(0, 1, 3, 2, 4).reshape(2, npad, pk.ldw)
+    assert torch.equal(back[:, : pk.cout_s], pk.w) and (back[:, pk.cout_s:] == 0).all()
+    for tile in (6, 7, 9, 14):
+        outs = []
+        for blocked in (True, False):
+            E.W_BLOCKED = blocked
+            try:
+                outs.append(E.conv(xc, pk, tile=tile).as_ncdhw(Cout).clone())
+            finally:
+                E.W_BLOCKED = True
+        _close(outs[0], ref.float(), 2e-5, "dma gemm, blocked weights, tile %d" % tile)
+        assert torch.equal(outs[0], outs[1]), "tile %d: blocked vs row-major weights" % tile
+
+
 X3D_AB_CASES = [
     # (N, Cin, Cmid, T, H, W): the four stride-1 block shapes of X3D-L (reduced frames) + ragged T / single frame
     (2, 24, 54, 5, 14, 28),      # s2: K = 24 (k32 step 3/4 used), 54 -> 56 stored, 2 chunks (second: 24 of 32 channels)
