@@ -106,6 +106,19 @@ __device__ __forceinline__ long plane_off(long m, int k, int kt) {
   return ((m >> 4) * kt + (k >> 5)) * 512 + (m & 15) * 32 + (k & 31);
 }
 
+// acc += x * w on four channels as TWO packed fp32 FMAs (v_pk_fma_f32, per-half operands: .xy and .zw of a float4 are aligned
+// register pairs).  The 7x7 depthwise kernels are VALU-bound on their 49 FMAs per output; the packed form halves the
+// instruction count with the same IEEE fma per element.  Only the PER-HALF form is used: the cross-half op_sel form is the one
+// that misbehaves beside MFMA kernels (tools/pk_overlap_probe.hip; tools/check_no_packed_f32.py guards it).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fma4(float4& acc, const float4& x, const float4& w) {
+  v2f a0 = {acc.x, acc.y}, a1 = {acc.z, acc.w};
+  const v2f x0 = {x.x, x.y}, x1 = {x.z, x.w}, w0 = {w.x, w.y}, w1 = {w.z, w.w};
+  a0 = __builtin_elementwise_fma(x0, w0, a0);
+  a1 = __builtin_elementwise_fma(x1, w1, a1);
+  acc.x = a0[0]; acc.y = a0[1]; acc.z = a1[0]; acc.w = a1[1];
+}
+
 __device__ __forceinline__ bool nonfinite(float v) { return !(fabsf(v) <= 3.4028235e38f); }
 __device__ __forceinline__ void report_nonfinite(int* status, bool bad) {
   if (bad && status) *reinterpret_cast<volatile int*>(status) = 1;   // idempotent: racing stores write the same value

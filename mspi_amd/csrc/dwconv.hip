@@ -277,10 +277,14 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const DwArgs p, int CG, in
 #pragma unroll
             for (int o = 0; o < SW; ++o) {
               const float4 xv = xin[o * STR + k];
-              acc[sh][o].x = fmaf(xv.x, wv.x, acc[sh][o].x);
-              acc[sh][o].y = fmaf(xv.y, wv.y, acc[sh][o].y);
-              acc[sh][o].z = fmaf(xv.z, wv.z, acc[sh][o].z);
-              acc[sh][o].w = fmaf(xv.w, wv.w, acc[sh][o].w);
+              if (K == 7) {
+                fma4(acc[sh][o], xv, wv);      // packed fp32 FMA (common.h): this kernel is VALU-bound at 7x7
+              } else {
+                acc[sh][o].x = fmaf(xv.x, wv.x, acc[sh][o].x);
+                acc[sh][o].y = fmaf(xv.y, wv.y, acc[sh][o].y);
+                acc[sh][o].z = fmaf(xv.z, wv.z, acc[sh][o].z);
+                acc[sh][o].w = fmaf(xv.w, wv.w, acc[sh][o].w);
+              }
             }
           }
         }
@@ -400,10 +404,14 @@ __global__ __launch_bounds__(256) void dw_lds_kernel(const DwArgs p, int CG, int
             const float4 wv = wt[(dh * K + k) * CG];
 #pragma unroll
             for (int o = 0; o < SW; ++o) {
-              acc[o].x = fmaf(x[o + k].x, wv.x, acc[o].x);
-              acc[o].y = fmaf(x[o + k].y, wv.y, acc[o].y);
-              acc[o].z = fmaf(x[o + k].z, wv.z, acc[o].z);
-              acc[o].w = fmaf(x[o + k].w, wv.w, acc[o].w);
+              if (K == 7) {
+                fma4(acc[o], x[o + k], wv);      // packed fp32 FMA (common.h): 7x7 -7 ... -9 % on 14 / 28-wide maps; 5x5x5 +3 ... +11 % (not used)
+              } else {
+                acc[o].x = fmaf(x[o + k].x, wv.x, acc[o].x);
+                acc[o].y = fmaf(x[o + k].y, wv.y, acc[o].y);
+                acc[o].z = fmaf(x[o + k].z, wv.z, acc[o].z);
+                acc[o].w = fmaf(x[o + k].w, wv.w, acc[o].w);
+              }
             }
           }
         }
