@@ -283,7 +283,6 @@ __global__ __launch_bounds__(256, (C == 96 && TM == 1) ? 2 : 1) void mlp_fused_k
     if (j + NS - 2 < p.nch) issue_stage(j + NS - 2);
   };
   int j = 1;
-#pragma unroll 2
   for (; j + 1 < p.nch; ++j) {
     top(j);
     body(yes(), yes(), j, smem + ((j - 1) % NS) * SB + lane * 16);

@@ -7,8 +7,10 @@ from mspi_amd import engine as E, testing as T
 from mspi_amd.model.model_utils import AudioVisualSaliencyModel
 name = sys.argv[1] if len(sys.argv) > 1 else "x3dl"
 dev = torch.device("cuda")
-t_tok = {"x3dl": 16, "slowfast4x16": 4, "mvitv2s": 8, "videoswint": 8, "videoswins": 8, "s3d": 4, "uniformer": 8, "morphmlp": 8}.get(name, 16)
-cfg = T.make_cfg(name, num_aud_tokens=9 * ((300 + 31) // 32), num_vis_tokens=t_tok * 49)
+label = name
+name, depths = {"videoswint": ("videoswins", [2, 2, 6, 2])}.get(label, (label, None))
+t_tok = {"x3dl": 16, "slowfast4x16": 4, "s3d": 4}.get(name, 8)
+cfg = T.make_cfg(name, num_aud_tokens=9 * ((300 + 31) // 32), num_vis_tokens=t_tok * 49, swin_depths=depths)
 so, sys.stdout = sys.stdout, io.StringIO()
 try:
     model = T.condition_(T.seeded(lambda: AudioVisualSaliencyModel(cfg), 0), name).to(dev)
