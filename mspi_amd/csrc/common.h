@@ -112,6 +112,10 @@ __device__ __forceinline__ long plane_off(long m, int k, int kt) {
 // that misbehaves beside MFMA kernels (tools/pk_overlap_probe.hip; tools/check_no_packed_f32.py guards it).
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void fma4(float4& acc, const float4& x, const float4& w) {
+#ifdef MSPI_DW_NO_PK      // A/B build: the scalar form
+  acc.x = fmaf(x.x, w.x, acc.x); acc.y = fmaf(x.y, w.y, acc.y); acc.z = fmaf(x.z, w.z, acc.z); acc.w = fmaf(x.w, w.w, acc.w);
+  return;
+#endif
   v2f a0 = {acc.x, acc.y}, a1 = {acc.z, acc.w};
   const v2f x0 = {x.x, x.y}, x1 = {x.z, x.w}, w0 = {w.x, w.y}, w1 = {w.z, w.w};
   a0 = __builtin_elementwise_fma(x0, w0, a0);
