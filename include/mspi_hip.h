@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSPI_ABI_VERSION 1
+#define MSPI_ABI_VERSION 2   /* 2: blocked plane layout (mspi_gemm_sp_fwd and friends), MspiConvDesc.w_blocked */
 
 typedef void* mspi_stream_t; /* hipStream_t */
 

@@ -189,8 +189,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.mspi_version() != 1:
-        raise MspiError("libmspi_hip.so ABI version %d != 1" % lib.mspi_version())
+    if lib.mspi_version() != 2:
+        raise MspiError("libmspi_hip.so ABI version %d != 2" % lib.mspi_version())
     _lib = lib
     return lib
 

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert getattr(raw, name) is not None
-    assert lib.mspi_version() == 1
+    assert lib.mspi_version() == 2
     assert lib.mspi_last_error() is not None
 
 
