@@ -46,12 +46,16 @@ struct MlpArgs {
 // Packed weight stage (one hidden chunk j of 32 units), all f16, 1 KB = 64 lanes x 8 halves per fragment:
 //   W1 part: [ks = 0..C/16)[plane hi,lo][lane][e]   = W1s[j*32 + lane%32][16*ks + 8*(lane/32) + e]
 //   W2 part: [s = 0..2)[ct = 0..C/32)[plane][lane][e] = W2s[ct*32 + lane%32][j*32 + (2*s + e/4)*8 + 4*(lane/32) + e%4]
-template <int C, int TM, int NS>
-__global__ __launch_bounds__(256, (C == 96 && TM == 1) ? 2 : 1) void mlp_fused_kernel(const MlpArgs p) {
+// NWV waves per workgroup (4 or 8) share one weight ring: 8 waves (256 rows) halve the weight stream per row -- every workgroup
+// pulls the WHOLE layer pair through LDS-DMA (1.15 MB at C = 192), and that issue is what the 4-wave loop spends most of its
+// non-MFMA time on.
+template <int C, int TM, int NS, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, (C == 96 && TM == 1 && NWV == 4) ? 2 : 1) void mlp_fused_kernel(const MlpArgs p) {
   constexpr int KS = C / 16, CT = C / 32;
   constexpr int W1B = KS * 2048, W2B = 2 * CT * 2048, SB = W1B + W2B;   // bytes per stage
-  constexpr int DPW = SB / 4096;                                        // DMA instructions per wave per stage
-  constexpr int BM = 4 * 32 * TM;
+  constexpr int DPW = SB / (1024 * NWV);                                // DMA instructions per wave per stage
+  constexpr int BM = NWV * 32 * TM;
+  static_assert(SB % (1024 * NWV) == 0, "a stage is dealt in whole 1-KB pieces to the waves");
   static_assert(C % 32 == 0 && SB % 4096 == 0, "C: multiple of 32");
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * SB + (C == 96 ? 2048 : 4096)];   // the ring, then b1 (hidden <= 1024 floats)
   float* b1s = reinterpret_cast<float*>(smem + NS * SB);
@@ -81,7 +85,8 @@ __global__ __launch_bounds__(256, (C == 96 && TM == 1) ? 2 : 1) void mlp_fused_k
   // W1 of chunks 0 and 1 go to the two halves of the last slot (W1B == W2B), which the ring first overwrites at the top of
   // iteration 1, after both have been consumed (prologue, iteration 0)
   static_assert(W1B == W2B, "the prologue parks W1 of chunk 1 in a W2 half");
-  constexpr int DP0 = W1B / 4096;
+  constexpr int DP0 = W1B / (1024 * NWV);
+  static_assert(W1B % (1024 * NWV) == 0, "W1 of a chunk is dealt in whole pieces");
   auto issue_w1_01 = [&]() {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256, (C == 96 && TM == 1) ? 2 : 1) void mlp_fused_k
   static_assert(NS >= 3, "the pipeline keeps stage j-1 in use while stage j is in flight and the prologue's slot is live");
   issue_w1_01();
   for (int j = 0; j < NS - 1; ++j) issue_stage(j < p.nch ? j : 0);     // always NS-1 stages: uniform DMA counts
-  for (int i = tid; i < p.nch * 32; i += 256) b1s[i] = p.b1[i];
+  for (int i = tid; i < p.nch * 32; i += 64 * NWV) b1s[i] = p.b1[i];
 
   if (p.ln) {
 #pragma unroll
@@ -344,11 +349,11 @@ __global__ __launch_bounds__(256, (C == 96 && TM == 1) ? 2 : 1) void mlp_fused_k
   report_nonfinite(p.status, bad);
 }
 
-template <int C, int TM, int NS>
+template <int C, int TM, int NS, int NWV = 4>
 static int launch_mlp(const MlpArgs& a, hipStream_t s) {
-  constexpr int BM = 128 * TM;
+  constexpr int BM = 32 * NWV * TM;
   const long nb = (a.M + BM - 1) / BM;
-  hipLaunchKernelGGL((mlp_fused_kernel<C, TM, NS>), dim3((unsigned)nb), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((mlp_fused_kernel<C, TM, NS, NWV>), dim3((unsigned)nb), dim3(64 * NWV), 0, s, a);
   return 0;
 }
 
@@ -383,6 +388,9 @@ extern "C" int mspi_mlp_fwd(const MspiMlpDesc* d, const void* x, const void* gam
   MSPI_REQUIRE(d->C != 96 || d->hidden <= 512, "mspi_mlp_fwd: hidden = %d > 512 with C = 96", d->hidden);
   if (d->C == 96) rc = (variant == 2) ? launch_mlp<96, 2, 4>(a, (hipStream_t)stream) :
                        launch_mlp<96, 1, 3>(a, (hipStream_t)stream);
+  // C = 192: 8 waves (256 rows) per workgroup where that still gives every CU a workgroup (measured at M = 100352: 315.9 ->
+  // 277.6 us); MSPI_MLP_TM=4 / 8 force one form for an A/B
+  else if (variant == 8 || (variant != 4 && a.M >= 256L * 256)) rc = launch_mlp<192, 1, 3, 8>(a, (hipStream_t)stream);
   else rc = launch_mlp<192, 1, 3>(a, (hipStream_t)stream);
   (void)rc;
   return check_launch("mspi_mlp_fwd");
