@@ -14,6 +14,7 @@
 //     k = 16h + 8s .. +7 for both operands (a dot product does not care);
 //   * double buffered: the DMA of stage it+1 flies under the MFMAs of stage it, one barrier per stage.
 #include "conv_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace mspi {
@@ -308,7 +309,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  // The activation is dispatched ONCE, outside the element loops: with `p.act` looked at per element the compiler kept the
+  // whole switch (scalar compares and branches, the sigmoid's IEEE division) around each of the 16 * TN values.
   bool bad = false;
+  auto epilogue = [&](auto act_c) {
+  constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + j * 32 + li;
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
           const int r = 2 * q + e;
           const float pre = acc[j][r] * p.out_scale + bv + rv[r];
           bad |= rb0 + (r & 3) + 8 * (r >> 2) < p.M && nonfinite(pre);      // padding rows are never flagged
-          const float v = act_apply(pre, p.act);
+          const float v = act_apply(pre, ACT);
           _Float16 h, l;
           split_f16(v, h, l);
           h2 pr = {h, l};
@@ -366,8 +371,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
       const int row = rb0 + (r & 3) + 8 * (r >> 2);
       const float pre = acc[j][r] * p.out_scale + bv + rv[r];
       bad |= row < p.M && nonfinite(pre);
-      if (row < p.M) p.y[(long)row * p.ldy + col] = act_apply(pre, p.act);
+      if (row < p.M) p.y[(long)row * p.ldy + col] = act_apply(pre, ACT);
     }
+  }
+  };
+  switch (p.act) {
+    case MSPI_ACT_RELU: epilogue(std::integral_constant<int, MSPI_ACT_RELU>()); break;
+    case MSPI_ACT_GELU: epilogue(std::integral_constant<int, MSPI_ACT_GELU>()); break;
+    case MSPI_ACT_SIGMOID: epilogue(std::integral_constant<int, MSPI_ACT_SIGMOID>()); break;
+    case MSPI_ACT_SWISH: epilogue(std::integral_constant<int, MSPI_ACT_SWISH>()); break;
+    default: epilogue(std::integral_constant<int, MSPI_ACT_NONE>()); break;
   }
   report_nonfinite(p.status, bad);
 }
