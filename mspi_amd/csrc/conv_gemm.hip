@@ -11,6 +11,7 @@
 // fragment reads (lane (i,h) takes k = 4h..4h+3 of row i: the MFMA K order is permuted
 // identically for A and B, which a dot product does not care about) are conflict-free.
 #include "conv_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace mspi {
@@ -346,7 +347,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  // the activation is dispatched once, outside the element loops (see conv_gemm_ad.hip)
   bool bad = false;
+  auto epilogue = [&](auto act_c) {
+  constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + li;
@@ -371,9 +375,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
         const int row = rb0 + (r & 3) + 8 * (r >> 2);
         const float v = (PREC == PREC_F32 ? acc[i][j][r] : acc[i][j][r] * p.out_scale) + bv + rv[r];
         bad |= row < p.M && nonfinite(v);          // padding rows of the last tile carry no result: never flagged
-        if (row < p.M) p.y[(long)row * p.ldy + col] = act_apply(v, p.act);
+        if (row < p.M) p.y[(long)row * p.ldy + col] = act_apply(v, ACT);
       }
     }
+  }
+  };
+  switch (p.act) {
+    case MSPI_ACT_RELU: epilogue(std::integral_constant<int, MSPI_ACT_RELU>()); break;
+    case MSPI_ACT_GELU: epilogue(std::integral_constant<int, MSPI_ACT_GELU>()); break;
+    case MSPI_ACT_SIGMOID: epilogue(std::integral_constant<int, MSPI_ACT_SIGMOID>()); break;
+    case MSPI_ACT_SWISH: epilogue(std::integral_constant<int, MSPI_ACT_SWISH>()); break;
+    default: epilogue(std::integral_constant<int, MSPI_ACT_NONE>()); break;
   }
   report_nonfinite(p.status, bad);
 }
