@@ -433,7 +433,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + c); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
     if (res) { const float4 b = *reinterpret_cast<const float4*>(res + row * ldr + c); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
     bad |= nonfinite(a.x) | nonfinite(a.y) | nonfinite(a.z) | nonfinite(a.w);
-    a.x = act_apply(a.x, act); a.y = act_apply(a.y, act); a.z = act_apply(a.z, act); a.w = act_apply(a.w, act);
+    if (act != MSPI_ACT_NONE) {
+      auto fin = [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        a.x = act_apply(a.x, ACT); a.y = act_apply(a.y, ACT); a.z = act_apply(a.z, ACT); a.w = act_apply(a.w, ACT);
+      };
+      MSPI_DISPATCH_ACT(act, fin)
+    }
     *reinterpret_cast<float4*>(y + row * ldy + c) = a;
   }
   report_nonfinite(status, bad);

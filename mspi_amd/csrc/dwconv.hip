@@ -99,10 +99,11 @@ __global__ __launch_bounds__(256) void dw_kernel(const DwArgs p) {
       }
     }
     if (!IS_MAX) {
-      acc.x = act_apply(acc.x, p.act);
-      acc.y = act_apply(acc.y, p.act);
-      acc.z = act_apply(acc.z, p.act);
-      acc.w = act_apply(acc.w, p.act);
+      auto fin = [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        acc.x = act_apply(acc.x, ACT); acc.y = act_apply(acc.y, ACT); acc.z = act_apply(acc.z, ACT); acc.w = act_apply(acc.w, ACT);
+      };
+      MSPI_DISPATCH_ACT(p.act, fin)
     }
     const long orow = (((long)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
     *reinterpret_cast<float4*>(p.y + orow * p.ldy + cv * 4) = acc;
@@ -184,15 +185,19 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(const DwArgs p) {
       }
     }
     const long orow = (((long)n * p.To + to) * p.Ho + ho) * p.Wo + wo0;
+    auto fin = [&](auto act_c) {      // the activation as a compile-time constant inside the loop (common.h)
+      constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-    for (int o = 0; o < SW; ++o) {
-      if (wo0 + o < p.Wo) {
-        float4 v = acc[o];
-        if (POOL) { psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w; }
-        v.x = act_apply(v.x, p.act); v.y = act_apply(v.y, p.act); v.z = act_apply(v.z, p.act); v.w = act_apply(v.w, p.act);
-        *reinterpret_cast<float4*>(p.y + (orow + o) * p.ldy + cv * 4) = v;
+      for (int o = 0; o < SW; ++o) {
+        if (wo0 + o < p.Wo) {
+          float4 v = acc[o];
+          if (POOL) { psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w; }
+          v.x = act_apply(v.x, ACT); v.y = act_apply(v.y, ACT); v.z = act_apply(v.z, ACT); v.w = act_apply(v.w, ACT);
+          *reinterpret_cast<float4*>(p.y + (orow + o) * p.ldy + cv * 4) = v;
+        }
       }
-    }
+    };
+    MSPI_DISPATCH_ACT(p.act, fin)
   }
   if (POOL) {
     stage[threadIdx.x] = psum;
@@ -290,20 +295,24 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const DwArgs p, int CG, in
         }
       }
     }
+    auto fin = [&](auto act_c) {      // the activation as a compile-time constant inside the loops (common.h)
+      constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-    for (int sh = 0; sh < SH; ++sh) {
-      if (ho0 + sh >= p.Ho) continue;
-      const long orow = (((long)n * p.To + to) * p.Ho + ho0 + sh) * p.Wo + wo0;
+      for (int sh = 0; sh < SH; ++sh) {
+        if (ho0 + sh >= p.Ho) continue;
+        const long orow = (((long)n * p.To + to) * p.Ho + ho0 + sh) * p.Wo + wo0;
 #pragma unroll
-      for (int o = 0; o < SW; ++o) {
-        if (wo0 + o < p.Wo) {
-          float4 v = acc[sh][o];
-          if (POOL) { psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w; }
-          v.x = act_apply(v.x, p.act); v.y = act_apply(v.y, p.act); v.z = act_apply(v.z, p.act); v.w = act_apply(v.w, p.act);
-          *reinterpret_cast<float4*>(p.y + (orow + o) * p.ldy + cv * 4) = v;
+        for (int o = 0; o < SW; ++o) {
+          if (wo0 + o < p.Wo) {
+            float4 v = acc[sh][o];
+            if (POOL) { psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w; }
+            v.x = act_apply(v.x, ACT); v.y = act_apply(v.y, ACT); v.z = act_apply(v.z, ACT); v.w = act_apply(v.w, ACT);
+            *reinterpret_cast<float4*>(p.y + (orow + o) * p.ldy + cv * 4) = v;
+          }
         }
       }
-    }
+    };
+    MSPI_DISPATCH_ACT(p.act, fin)
   }
   if (POOL) {
     stage[tid] = psum;
@@ -417,15 +426,19 @@ __global__ __launch_bounds__(256) void dw_lds_kernel(const DwArgs p, int CG, int
         }
       }
       const long orow = (((long)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
+      auto fin = [&](auto act_c) {      // the activation as a compile-time constant inside the loop (common.h)
+        constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-      for (int o = 0; o < SW; ++o) {
-        if (wo + o < p.Wo) {
-          float4 v = acc[o];
-          if (POOL) { psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w; }
-          v.x = act_apply(v.x, p.act); v.y = act_apply(v.y, p.act); v.z = act_apply(v.z, p.act); v.w = act_apply(v.w, p.act);
-          *reinterpret_cast<float4*>(p.y + (orow + o) * p.ldy + cv * 4) = v;
+        for (int o = 0; o < SW; ++o) {
+          if (wo + o < p.Wo) {
+            float4 v = acc[o];
+            if (POOL) { psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w; }
+            v.x = act_apply(v.x, ACT); v.y = act_apply(v.y, ACT); v.z = act_apply(v.z, ACT); v.w = act_apply(v.w, ACT);
+            *reinterpret_cast<float4*>(p.y + (orow + o) * p.ldy + cv * 4) = v;
+          }
         }
-      }
+      };
+      MSPI_DISPATCH_ACT(p.act, fin)
     }
   }
   if (POOL) {

@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const float rstd = rsqrtf(q / (float)C + eps);
   float* yr = y + n * sNy + (long)r * ldy;
   const float* tr = table ? table + (long)r * C : nullptr;
+  auto fin = [&](auto act_c) {      // the activation as a compile-time constant inside the loop (common.h)
+  constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
   for (int j = 0; j < VPT; ++j) {
     const int i = sub + LPR * j;
@@ -61,10 +63,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       const float4 g = *reinterpret_cast<const float4*>(gamma + i * 4);
       const float4 b = *reinterpret_cast<const float4*>(beta + i * 4);
       float4 o;
-      o.x = act_apply((v[j].x - mean) * rstd * g.x + b.x, act);
-      o.y = act_apply((v[j].y - mean) * rstd * g.y + b.y, act);
-      o.z = act_apply((v[j].z - mean) * rstd * g.z + b.z, act);
-      o.w = act_apply((v[j].w - mean) * rstd * g.w + b.w, act);
+      o.x = act_apply((v[j].x - mean) * rstd * g.x + b.x, ACT);
+      o.y = act_apply((v[j].y - mean) * rstd * g.y + b.y, ACT);
+      o.z = act_apply((v[j].z - mean) * rstd * g.z + b.z, ACT);
+      o.w = act_apply((v[j].w - mean) * rstd * g.w + b.w, ACT);
       if (tr) {
         const float4 t = *reinterpret_cast<const float4*>(tr + i * 4);
         o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
@@ -83,6 +85,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       }
     }
   }
+  };
+  MSPI_DISPATCH_ACT(act, fin)
 }
 
 // ------------------------------------------------------------------ SE gate
@@ -180,7 +184,11 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
       o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
     }
     if (act != MSPI_ACT_NONE) {
-      o.x = act_apply(o.x, act); o.y = act_apply(o.y, act); o.z = act_apply(o.z, act); o.w = act_apply(o.w, act);
+      auto fin = [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        o.x = act_apply(o.x, ACT); o.y = act_apply(o.y, ACT); o.z = act_apply(o.z, ACT); o.w = act_apply(o.w, ACT);
+      };
+      MSPI_DISPATCH_ACT(act, fin)
     }
     *reinterpret_cast<float4*>(d) = o;
   }
