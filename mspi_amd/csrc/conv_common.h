@@ -43,6 +43,8 @@ struct ConvArgs {
   float* ws;        // ... and writes its partial sums to ws[z][M][Cout] (no bias / residual / activation); NULL: no split
   // pre-split activations (conv_gemm_dma_kernel<..., APRE>): A is two BLOCKED f16 planes (common.h plane_off; ldxs == K) (hi, then lo `xplane` elements
   // later), written by a producer's epilogue; the kernel then DMAs them like the weight planes and splits nothing
+  int dense_rows;       // 1: 1x1x1 / stride 1 / no padding on an input whose (n,t,h,w) positions are equally spaced rows (offset = m * sW):
+                        // the loaders skip the per-row integer divisions of the general gather
   const _Float16* wb;   // blocked f16 hi/lo weight planes (common.h plane_off; rows padded to 16), or NULL: the LDS-DMA kernels' weight source
   const _Float16* xs;
   long ldxs, xplane;

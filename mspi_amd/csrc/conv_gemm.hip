@@ -63,6 +63,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
     int m = m0 + rbase + RP * i;
     a_ok[i] = m < p.M;
     if (!a_ok[i]) m = 0;
+    if (p.dense_rows) {      // rows of a matrix: no (n, t, h, w) decomposition (three integer divisions per row otherwise)
+      a_n[i] = p.gate ? m / p.rows_per_sample : 0;      // (the squeeze-excite gate is per sample)
+      a_t[i] = 0; a_h[i] = 0; a_w[i] = 0;
+      a_off[i] = (long)m * p.sW;
+      continue;
+    }
     int wo = m % p.Wo;
     int t1 = m / p.Wo;
     int ho = t1 % p.Ho;
@@ -489,6 +495,9 @@ static int conv_fwd_impl(const MspiConvDesc* d, const float* x, const float* w, 
   static const int dbg = getenv("MSPI_CONV_DBG") ? atoi(getenv("MSPI_CONV_DBG")) : 0;
   a.dbg = dbg;
   a.ws = ws; a.ksplit = ksplit;
+  a.dense_rows = (d->kT == 1 && d->kH == 1 && d->kW == 1 && d->strT == 1 && d->strH == 1 && d->strW == 1 && d->padT == 0 && d->padH == 0 &&
+                  d->padW == 0 && d->sC == 1 && d->sH == (int64_t)d->W * d->sW && d->sT == (int64_t)d->H * d->sH &&
+                  d->sN == (int64_t)d->T * d->sT) ? 1 : 0;
   a.wb = (d->prec == PREC_F16X3) ? (const _Float16*)d->w_blocked : nullptr; a.xs = nullptr; a.ldxs = 0; a.xplane = 0; a.ys = nullptr; a.ldys = 0; a.yplane = 0;
   if (ws) {
     // split-K (mspi_conv_splitk_fwd): 64x64 tiles, gridDim.y = ksplit slices of the K loop, then the ordered reduction
@@ -680,6 +689,7 @@ extern "C" int mspi_gemm_sp_fwd(const MspiConvDesc* d, const void* x_planes, int
   a.out_scale = 1.0f / d->w_scale;
   a.status = g_status_word;
   a.dbg = 0; a.ws = nullptr; a.ksplit = 1;
+  a.dense_rows = 1;
   a.wb = nullptr;      // (the pre-split form takes blocked weights through `w`)
   a.xs = (const _Float16*)x_planes; a.ldxs = ldx; a.xplane = xplane;
   a.ys = (_Float16*)y_planes; a.ldys = ldys; a.yplane = yplane;

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_gemm_dma_kernel(const ConvArg
     int m = m0 + (j * NW + wave) * 8 + (lane >> 3);
     a_ok[j] = m < p.M;
     if (!a_ok[j]) m = 0;
+    if (p.dense_rows) { a_t[j] = 0; a_h[j] = 0; a_w[j] = 0; a_off[j] = (long)m * p.sW; continue; }   // rows of a matrix: no integer divisions
     const int wo = m % p.Wo;
     const int t1 = m / p.Wo;
     const int ho = t1 % p.Ho;
