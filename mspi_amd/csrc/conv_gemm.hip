@@ -429,8 +429,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   const long total = M * (Cout >> 2);
   bool bad = false;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int c = (int)(idx % (Cout >> 2)) * 4;
     const long row = idx / (Cout >> 2);
+    const int c = (int)(idx - row * (Cout >> 2)) * 4;
     float4 a = *reinterpret_cast<const float4*>(ws + row * Cout + c);
     for (int z = 1; z < S; ++z) {
       const float4 b = *reinterpret_cast<const float4*>(ws + ((long)z * M + row) * Cout + c);

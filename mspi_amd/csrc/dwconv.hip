@@ -55,14 +55,16 @@ template <bool IS_MAX>
 __global__ __launch_bounds__(256) void dw_kernel(const DwArgs p) {
   int n, lb0;
   unit_per_xcd((long)blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, n, lb0, p.unit_xcd);
-  const long idx = (long)lb0 * 256 + threadIdx.x;
-  if (idx < p.per_sample) {
-    const int cv = (int)(idx % p.CV);
-    long pos = idx / p.CV;
-    const int wo = (int)(pos % p.Wo);
-    pos /= p.Wo;
-    const int ho = (int)(pos % p.Ho);
-    const int to = (int)(pos / p.Ho);
+  // 32-bit index arithmetic (per_sample < 2^31 - 256, checked on the host): as `long` each of these divisions is a ~100-instruction
+  // 64-bit sequence, four per thread -- beside a few hundred FMAs
+  const unsigned idx = (unsigned)lb0 * 256u + threadIdx.x;
+  if (idx < (unsigned)p.per_sample) {
+    const int cv = (int)(idx % (unsigned)p.CV);
+    unsigned pos = idx / (unsigned)p.CV;
+    const int wo = (int)(pos % (unsigned)p.Wo);
+    pos /= (unsigned)p.Wo;
+    const int ho = (int)(pos % (unsigned)p.Ho);
+    const int to = (int)(pos / (unsigned)p.Ho);
     const int t0 = to * p.strT - p.padT, h0 = ho * p.strH - p.padH, w0 = wo * p.strW - p.padW;
     const float* xb = p.x + ((long)n * p.T * p.H * p.W) * p.ldx + cv * 4;
     float4 acc;
@@ -120,18 +122,18 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(const DwArgs p) {
   const int nblk = gridDim.x;
   int n, lb;
   unit_per_xcd((long)blockIdx.y * nblk + blockIdx.x, nblk, gridDim.y, n, lb, p.unit_xcd);
-  const long idx0 = (long)lb * 256;
-  const long idx = idx0 + threadIdx.x;
+  const unsigned idx0 = (unsigned)lb * 256u;      // 32-bit index arithmetic (see dw_kernel)
+  const unsigned idx = idx0 + threadIdx.x;
   const int S = (p.Wo + SW - 1) / SW;
-  const long per_sample = (long)p.To * p.Ho * S * p.CV;
+  const unsigned per_sample = (unsigned)p.To * p.Ho * S * p.CV;
   float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (idx < per_sample) {
-    const int cv = (int)(idx % p.CV);
-    long pos = idx / p.CV;
-    const int ws = (int)(pos % S);
-    pos /= S;
-    const int ho = (int)(pos % p.Ho);
-    const int to = (int)(pos / p.Ho);
+    const int cv = (int)(idx % (unsigned)p.CV);
+    unsigned pos = idx / (unsigned)p.CV;
+    const int ws = (int)(pos % (unsigned)S);
+    pos /= (unsigned)S;
+    const int ho = (int)(pos % (unsigned)p.Ho);
+    const int to = (int)(pos / (unsigned)p.Ho);
     const int wo0 = ws * SW;
     const int t0 = to * p.strT - p.padT, h0 = ho * p.strH - p.padH, w0 = wo0 * SWS - p.padW;
     const float* xb = p.x + ((long)n * p.T * p.H * p.W) * p.ldx + cv * 4;
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(const DwArgs p) {
     for (int r = threadIdx.x; r < p.CV; r += 256) {
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int j = r; j < 256; j += p.CV) { s.x += stage[j].x; s.y += stage[j].y; s.z += stage[j].z; s.w += stage[j].w; }
-      const int cvr = (int)((idx0 + r) % p.CV);
+      const int cvr = (int)((idx0 + r) % (unsigned)p.CV);
       *reinterpret_cast<float4*>(p.pool + ((long)n * nblk + lb) * p.C + cvr * 4) = s;
     }
   }
@@ -237,13 +239,13 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const DwArgs p, int CG, in
   }
   __syncthreads();
   const int cvl = tid % CG, pl = tid / CG;
-  const long pos = (long)lb * PB + pl;
+  const unsigned pos = (unsigned)lb * PB + pl;      // 32-bit index arithmetic (see dw_kernel)
   const long npos = (long)p.To * HS * S;
   float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (pl < PB && pos < npos) {
-    const int ws = (int)(pos % S);
-    const int hs = (int)((pos / S) % HS);
-    const int to = (int)(pos / ((long)S * HS));
+    const int ws = (int)(pos % (unsigned)S);
+    const int hs = (int)((pos / (unsigned)S) % (unsigned)HS);
+    const int to = (int)(pos / ((unsigned)S * HS));
     const int cv = g * CG + cvl;
     const int wo0 = ws * SW, ho0 = hs * SH;
     const int t0 = to * p.strT - p.padT, h0 = ho0 * STR - p.padH, w0 = wo0 * STR - p.padW;
@@ -549,7 +551,7 @@ static int fill_args(const MspiDwConvDesc* d, DwArgs& a, const char* who) {
   a.per_sample = (long)To * Ho * Wo * a.CV;
   static const int unit_xcd = getenv("MSPI_DW_UNIT_XCD") ? atoi(getenv("MSPI_DW_UNIT_XCD")) : 1;
   a.unit_xcd = unit_xcd;
-  MSPI_REQUIRE((a.per_sample + 255) / 256 < (1L << 31) && d->N < 65536, "%s: grid too large", who);
+  MSPI_REQUIRE(a.per_sample < (1L << 31) - 256 && d->N < 65536, "%s: more than 2^31 outputs per sample", who);
   return MSPI_OK;
 }
 

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void rowgemm_kernel(const RowGemmArgs p) {
     xr[ks][4] = k1 ? b.x : 0.f; xr[ks][5] = k1 ? b.y : 0.f; xr[ks][6] = k1 ? b.z : 0.f; xr[ks][7] = k1 ? b.w : 0.f;
   }
   if (GATE) {
-    const float* gp = p.gate + (rr / p.rows_per_sample) * p.ldg + 8 * lh;
+    const float* gp = p.gate + (long)((unsigned)rr / (unsigned)p.rows_per_sample) * p.ldg + 8 * lh;   // 32-bit division (M < 2^31)
 #pragma unroll
     for (int ks = 0; ks < KSB; ++ks) {
       const int k = 16 * ks + 8 * lh;
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256, 1) void x3d_ca_kernel(const CaArgs p) {
     xr[ks][4] = k1 ? b.x : 0.f; xr[ks][5] = k1 ? b.y : 0.f; xr[ks][6] = k1 ? b.z : 0.f; xr[ks][7] = k1 ? b.w : 0.f;
   }
   if (GATE) {
-    const float* gp = p.gate + (rr / p.rows_per_sample) * p.ldg + 8 * lh;
+    const float* gp = p.gate + (long)((unsigned)rr / (unsigned)p.rows_per_sample) * p.ldg + 8 * lh;   // 32-bit division (M < 2^31)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int k = 16 * ks + 8 * lh;

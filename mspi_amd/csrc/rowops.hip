@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
   const bool rok = row < M;
   const long rr = rok ? row : 0;
-  const long n = rr / R;
+  const long n = (long)((unsigned)rr / (unsigned)R);      // 32-bit division (M < 2^31, checked on the host): the 64-bit form is ~100 instructions
   const int r = (int)(rr - n * R);
   const int nv = C >> 2;
   const float* xr = x + n * sNx + (long)r * ldx;
@@ -154,12 +154,14 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
   const long total = (long)NT * Ho * Wo * CV;
   const float inv = 1.f / (float)k;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int cv = (int)(idx % CV);
-    long pos = idx / CV;
-    const int wo = (int)(pos % Wo);
-    pos /= Wo;
-    const int ho = (int)(pos % Ho);
-    const long nt = pos / Ho;
+    // 32-bit index arithmetic (total < 2^31, checked on the host): four 64-bit divisions per output vector otherwise
+    const unsigned ui = (unsigned)idx;
+    const int cv = (int)(ui % (unsigned)CV);
+    unsigned pos = ui / (unsigned)CV;
+    const int wo = (int)(pos % (unsigned)Wo);
+    pos /= (unsigned)Wo;
+    const int ho = (int)(pos % (unsigned)Ho);
+    const long nt = (long)(pos / (unsigned)Ho);
     float fh = ((float)ho + 0.5f) * inv - 0.5f;
     float fw = ((float)wo + 0.5f) * inv - 0.5f;
     fh = fh < 0.f ? 0.f : fh;
@@ -355,6 +357,7 @@ static int layernorm_impl(const float* x, int64_t ldx, int64_t sNx, float* y, in
                           int32_t act, const float* table, mspi_stream_t stream, const char* who) {
   MSPI_REQUIRE(x && (y || planes) && gamma && beta, "%s: null argument", who);
   const int64_t M = (int64_t)N * R;
+  MSPI_REQUIRE(M < (1L << 31), "%s: more than 2^31 rows", who);
   MSPI_REQUIRE(N > 0 && R > 0 && C > 0 && (C & 3) == 0 && C <= LN_MAXC, "%s: C=%d must be a multiple of 4, <= %d", who, C, LN_MAXC);
   MSPI_REQUIRE((ldx & 3) == 0 && ldx >= C && (sNx & 3) == 0, "%s: bad input row/sample stride", who);
   MSPI_REQUIRE(planes || ((ldy & 3) == 0 && ldy >= C && (sNy & 3) == 0 && aligned16(y)), "%s: bad output row/sample stride", who);
@@ -413,6 +416,7 @@ extern "C" int mspi_upsample_fwd(const float* src, int64_t lds, float* dst, int6
   MSPI_REQUIRE((C & 3) == 0 && (lds & 3) == 0 && (ldd & 3) == 0 && lds >= C && ldd >= C && aligned16(src) && aligned16(dst),
                "mspi_upsample_fwd: C/ld must be multiples of 4, pointers 16-B aligned");
   const long total = (long)NT * H * factor * W * factor * (C / 4);
+  MSPI_REQUIRE(total < (1L << 31), "mspi_upsample_fwd: more than 2^31 output vectors");
   hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, (long)lds, dst,
                      (long)ldd, NT, H, W, C / 4, factor, accumulate, act);
   return check_launch("mspi_upsample_fwd");
