@@ -499,8 +499,9 @@ def main():
         kname, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
         tflops = d["flops"] / d["ms"] / 1e9
         gbs = d["bytes"] / d["ms"] / 1e6
-        mfma_bound = kname.startswith("conv_gemm") or kname == "attention"
-        f16x3 = "f16x3" in kname
+        # the fused MLP (mspi_mlp_fwd) and attention are f16x3 matrix-pipe kernels like the GEMMs (their names carry no tile string)
+        mfma_bound = kname.startswith("conv_gemm") or kname in ("attention", "mlp_fused")
+        f16x3 = "f16x3" in kname or (kname in ("attention", "mlp_fused") and E.DEFAULT_PREC == E.PREC_F16X3)
         peak = F16_MFMA_PEAK_TFLOPS if f16x3 else FP32_MFMA_PEAK_TFLOPS
         # which roof is nearer is judged by how busy the unit is: an f16x3 kernel keeps the matrix pipe 3x as busy as its
         # algorithmic flops say; `achieved` / `frac` below stay ALGORITHMIC flops against the dense f16 peak
