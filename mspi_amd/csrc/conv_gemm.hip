@@ -102,7 +102,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const ConvAr
   const int it_begin = p.ws ? (int)((long)nk * blockIdx.y / p.ksplit) : 0;
   const int it_end = p.ws ? (int)((long)nk * (blockIdx.y + 1) / p.ksplit) : nk;
   int kc = kv * 4 + it_begin * BK, ktap = 0, kdt = 0, kdh = 0, kdw = 0;
-  if (LOADER == LOAD_V4) {
+  if (LOADER == LOAD_V4 && p.dense_rows && it_begin == 0) {
+    // one tap, cursor inside the first k-step: no divisions (kc < 32 <= ... ; past C it points at the zero padding of the weights)
+    if (kc >= p.C) { kc -= p.C; ktap = 1; }
+  } else if (LOADER == LOAD_V4) {
     ktap = kc / p.C;
     kc -= ktap * p.C;
     int khw = p.kH * p.kW;
