@@ -27,6 +27,14 @@ def test_library_exports_every_declared_symbol():
     assert lib.mspi_last_error() is not None
 
 
+def test_graft_entry_build_runs_without_gpu():
+    """The driver's build check: make + load + ABI version against the header (the assert once went stale on a version bump)."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    importlib.import_module("__graft_entry__").build()
+
+
 def test_descriptor_validation_without_gpu():
     """Bad descriptors are rejected on the host before any launch (no GPU needed)."""
     from mspi_amd import _lib
