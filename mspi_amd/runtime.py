@@ -66,7 +66,10 @@ class GraphPipeline:
         self._count = 0
         self.layout = None
         self.after = None       # optional callable(slot_index, outs), run on the slot's stream right behind each replay
-        trials = max(1, int(layouts)) if self.depth > 1 else 1
+        # the creation-order trials exist for depth 2 (and work at 3); at depth 4 the fourth trial took the HIP runtime down
+        # with a segmentation fault inside hipGraphLaunch (ROCm 7.2, 16 graph branches on 6 queues) -- and depth > 2 is slower
+        # than depth 2 anyway (bench line 665 / 536 clips/s at depth 2 / 3, same box), so deeper pipelines skip the trials
+        trials = max(1, int(layouts)) if 1 < self.depth <= 3 else 1
         best = None
         for skip in range(trials):
             held = [torch.cuda.Stream() for _ in range(skip)]      # shifts the creation order = the hardware-queue mapping
