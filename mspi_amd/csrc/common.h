@@ -78,12 +78,19 @@ __device__ __forceinline__ float gelu_erf(float u) {
   return u >= 0.f ? u - r : r;
 }
 
+// sigmoid / swish on v_exp_f32 + v_rcp_f32 (1 ulp each): the IEEE `/` expands to a ~10-instruction div_scale / fma / div_fixup
+// sequence per element, which was most of the VALU work of the X3D depthwise epilogues and of the gate prologues.
+__device__ __forceinline__ float fast_sigmoid(float v) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+}
+__device__ __forceinline__ float fast_swish(float v) { return v * fast_sigmoid(v); }
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
     case MSPI_ACT_RELU: return fmaxf(v, 0.f);
     case MSPI_ACT_GELU: return gelu_erf(v);  // nn.GELU (erf form)
-    case MSPI_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
-    case MSPI_ACT_SWISH: return v / (1.f + __expf(-v));
+    case MSPI_ACT_SIGMOID: return fast_sigmoid(v);
+    case MSPI_ACT_SWISH: return fast_swish(v);
     default: return v;
   }
 }

@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void rowgemm_kernel(const RowGemmArgs p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float v = xr[ks][e] * g8[e];
-        xr[ks][e] = v / (1.f + __expf(-v));     // Swish (zero stays zero: masked k contribute nothing)
+        xr[ks][e] = fast_swish(v);     // Swish (zero stays zero: masked k contribute nothing)
       }
     }
   }
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(256, 1) void x3d_ca_kernel(const CaArgs p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float v = xr[ks][e] * g8[e];
-        xr[ks][e] = v / (1.f + __expf(-v));     // Swish (zero stays zero: masked k contribute nothing)
+        xr[ks][e] = fast_swish(v);     // Swish (zero stays zero: masked k contribute nothing)
       }
     }
   }

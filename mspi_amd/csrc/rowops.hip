@@ -141,7 +141,7 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(const float* __restrict__
   for (int c = threadIdx.x; c < C; c += 1024) {
     float s = b2[c];
     for (int f = 0; f < F; ++f) s = fmaf(w2[(long)c * F + f], hid[f], s);
-    gate[(long)n * C + c] = 1.f / (1.f + __expf(-s));
+    gate[(long)n * C + c] = fast_sigmoid(s);
   }
 }
 

@@ -193,8 +193,7 @@ __global__ __launch_bounds__(256, 2) void x3d_ab_kernel(const X3dAbArgs p) {
           float4 v = acc[j];
           psum.x += v.x; psum.y += v.y; psum.z += v.z; psum.w += v.w;
           if (p.act == MSPI_ACT_SWISH) {
-            v.x = v.x / (1.f + __expf(-v.x)); v.y = v.y / (1.f + __expf(-v.y));
-            v.z = v.z / (1.f + __expf(-v.z)); v.w = v.w / (1.f + __expf(-v.w));
+            v.x = fast_swish(v.x); v.y = fast_swish(v.y); v.z = fast_swish(v.z); v.w = fast_swish(v.w);
           }
           if (cok) *reinterpret_cast<float4*>(up + (long)j * p.ldu) = v;
         }
