@@ -148,18 +148,6 @@ int mspi_dwconv_fwd(const MspiDwConvDesc* d, const float* x, const float* w, con
 /* partial-sum rows per sample that mspi_dwconv_fwd writes for this descriptor (-1: pooling unsupported) */
 int mspi_dwconv_pool_rows(const MspiDwConvDesc* d);
 
-/* mspi_dwconv_fwd with pooling AND the squeeze-excite gate in ONE launch: the last workgroup to arrive for a sample adds that
- * sample's partial rows (fixed order: bitwise reproducible) and writes gate[n,:] = sigmoid(fc2(relu(fc1(inv_count * sum))))
- * -- X3DTransform's `b` conv + b_bn + SE (SlowFast/resnet_helper.py:313-327, SE :27-73) without the separate mspi_se_gate
- * launch.  w1 [F][C], b1 [F], w2 [C][F], b2 [C], gate [N][C].  counters: N uint32 words of DEVICE memory that are ZERO when the
- * launch starts; the launch leaves them zero again, so one zero-initialised buffer serves every launch that is ordered on the
- * same stream -- launches that may run concurrently (other streams, other hipGraphs in flight) need buffers of their own.
- * mspi_dwconv_se_supported: 1 when the descriptor runs on the kernel that carries the fold (else: mspi_dwconv_fwd + mspi_se_gate). */
-int mspi_dwconv_se_supported(const MspiDwConvDesc* d, int32_t F);
-int mspi_dwconv_se_fwd(const MspiDwConvDesc* d, const float* x, const float* w, const float* bias, float* y,
-                       float* pool /*[N][rows][C] scratch*/, float inv_count, const float* w1, const float* b1,
-                       const float* w2, const float* b2, int32_t F, float* gate, uint32_t* counters, mspi_stream_t stream);
-
 /* Squeeze-excite gate: gate[n,c] = sigmoid(fc2(relu(fc1(inv_count * sum_r pool[n,r,:]))))
  * (SlowFast/resnet_helper.py:27-73).  w1 [F][C], b1 [F], w2 [C][F], b2 [C]. */
 int mspi_se_gate(const float* pool, int32_t rows, float inv_count, const float* w1, const float* b1,

@@ -119,8 +119,6 @@ _SIGNATURES = {
     "mspi_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "mspi_dwconv_fwd": (C.c_int, [C.POINTER(DwConvDesc), _P, _P, _P, _P, _P, _P]),
     "mspi_dwconv_pool_rows": (C.c_int, [C.POINTER(DwConvDesc)]),
-    "mspi_dwconv_se_supported": (C.c_int, [C.POINTER(DwConvDesc), C.c_int32]),
-    "mspi_dwconv_se_fwd": (C.c_int, [C.POINTER(DwConvDesc), _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "mspi_se_gate": (C.c_int, [_P, C.c_int32, C.c_float, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mspi_layernorm_fwd": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P, _P, C.c_float, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, _P, _P]),

@@ -193,16 +193,14 @@ class X3DTransform(HipModule):
         pk = self.pk
         se = "se" in pk
         # the fused kernel is built from `a`'s f16x3 planes: it follows that pack's first-sight range check
-        gate = None
         if t is None and self.uses_ab(x) and E.range_check_input(pk["a"], x):
             u = E.x3d_ab(x, pk["ab"], pool=se)
-            if se:
-                u, part = u
-                gate = E.se_gate(part, 1.0 / (u.T * u.H * u.W), *pk["se"])
-        elif se:     # depthwise conv + pooling + the squeeze-excite gate in one launch (the sample's last workgroup computes the gate)
-            u, gate = E.dwconv(E.conv(x, pk["a"]) if t is None else t, pk["b"], pool=True, se=pk["se"])
         else:
-            u = E.dwconv(E.conv(x, pk["a"]) if t is None else t, pk["b"])
+            u = E.dwconv(E.conv(x, pk["a"]) if t is None else t, pk["b"], pool=se)
+        gate = None
+        if se:
+            u, part = u
+            gate = E.se_gate(part, 1.0 / (u.T * u.H * u.W), *pk["se"])
         if seam is not None:
             return E.x3d_ca(u, seam, res, gate=gate)
         return E.conv(u, pk["c"], res=res, gate=gate, out=out)

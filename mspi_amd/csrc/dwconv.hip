@@ -25,101 +25,7 @@ struct DwArgs {
   int CV;          // C / 4
   long per_sample; // To*Ho*Wo*CV
   int unit_xcd;    // one unit (sample / sample x channel group) per XCD (A/B switch MSPI_DW_UNIT_XCD=0)
-  // squeeze-excite gate folded into the pooling launch (mspi_dwconv_se_fwd; se_gate == NULL: plain pooling)
-  const float* se_w1; const float* se_b1; const float* se_w2; const float* se_b2;
-  float* se_gate;
-  unsigned* se_count;   // [N] arrival counters: zero when the launch starts, zero again when it ends
-  int se_F;
-  float se_inv;
 };
-
-typedef unsigned int u32x4_dw __attribute__((ext_vector_type(4)));
-typedef float f32x4_dw __attribute__((ext_vector_type(4)));
-// `sc1` (agent-scope) 16-B accesses: the store is written through and leaves the XCD's L2, the load bypasses L1 -- the form a
-// cross-workgroup hand-off inside one launch needs (MI355X_MICROARCH.md "Valid forms", row 1).  The loaded vector is re-typed
-// as a whole: picking elements out of the builtin's result makes hipcc (ROCm 7.2) narrow the load to one dword.
-__device__ __forceinline__ float4 dw_ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  const f32x4_dw f = __builtin_bit_cast(f32x4_dw, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16));
-  return make_float4(f.x, f.y, f.z, f.w);
-}
-__device__ __forceinline__ void dw_st_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
-  const f32x4_dw f = {v.x, v.y, v.z, v.w};
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_dw, f), r, (int)byte_off, 0, 16);
-}
-
-constexpr int SE_MAX_C = 512, SE_MAX_F = 64;
-
-// The squeeze-excite gate of sample n, computed by the LAST workgroup of the pooling launch to arrive for that sample
-// (SlowFast/resnet_helper.py:27-73: mean over the sample -> fc1 -> ReLU -> fc2 -> sigmoid).  Replaces the separate
-// mspi_se_gate launch (10.6 us, 29 per X3D-L forward) by a tail on one workgroup per sample.  Bitwise reproducible: the
-// partial rows are added in a fixed order (thread (quad, part) takes rows part, part + PARTS, ... with 8 accumulators, the
-// parts are combined in order) whatever the arrival order was.  All 256 threads of the workgroup call this.
-__device__ void se_gate_tail(const DwArgs& p, int n, int rows) {
-  __shared__ __attribute__((aligned(16))) float se_part[1024];     // [PARTS][4 * QP]: PARTS * QP == 256
-  __shared__ __attribute__((aligned(16))) float se_mean[SE_MAX_C];
-  __shared__ float se_hid[SE_MAX_F];
-  const int tid = threadIdx.x;
-  const int NQ = p.CV, C = p.C, F = p.se_F;
-  int QP = 16;
-  while (QP < NQ) QP <<= 1;                 // 16 .. 128 (C <= 512)
-  const int PARTS = 256 / QP;
-  const int q = tid & (QP - 1), part = tid / QP;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.pool + (long)n * rows * C, 0, rows * C * 4, 0x00020000);
-  {
-    constexpr int NB = 24;      // rows in flight per thread: the sample's 95-686 rows are 2 batches of loads, not 6 (each ~2 us)
-    float4 a[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r0 = part; r0 < rows; r0 += NB * PARTS) {
-      float4 v[NB];
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {       // one batch of independent loads; out-of-range offsets read zeros
-        const int r = r0 + u * PARTS;
-        v[u] = dw_ld_sc1(rs, (q < NQ && r < rows) ? (unsigned)(r * C + 4 * q) * 4u : 0x80000000u);
-      }
-#pragma unroll
-      for (int u = 0; u < NB; ++u) { a[u & 3].x += v[u].x; a[u & 3].y += v[u].y; a[u & 3].z += v[u].z; a[u & 3].w += v[u].w; }
-    }
-    float4 s4;
-    s4.x = (a[0].x + a[1].x) + (a[2].x + a[3].x);
-    s4.y = (a[0].y + a[1].y) + (a[2].y + a[3].y);
-    s4.z = (a[0].z + a[1].z) + (a[2].z + a[3].z);
-    s4.w = (a[0].w + a[1].w) + (a[2].w + a[3].w);
-    *reinterpret_cast<float4*>(se_part + (part * QP + q) * 4) = s4;
-  }
-  __syncthreads();
-  if (tid < NQ) {
-    float4 s4 = *reinterpret_cast<const float4*>(se_part + tid * 4);
-    for (int i = 1; i < PARTS; ++i) {
-      const float4 v = *reinterpret_cast<const float4*>(se_part + (i * QP + tid) * 4);
-      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
-    }
-    s4.x *= p.se_inv; s4.y *= p.se_inv; s4.z *= p.se_inv; s4.w *= p.se_inv;
-    *reinterpret_cast<float4*>(se_mean + tid * 4) = s4;
-  }
-  __syncthreads();
-  {   // fc1 + ReLU: 8 lanes per hidden unit, 32 units per pass
-    const int sub = tid & 7;
-    for (int f0 = 0; f0 < F; f0 += 32) {
-      const int f = f0 + (tid >> 3);
-      float s = 0.f;
-      if (f < F)
-        for (int qq = sub; qq < NQ; qq += 8) {
-          const float4 w = *reinterpret_cast<const float4*>(p.se_w1 + (long)f * C + 4 * qq);
-          const float4 m = *reinterpret_cast<const float4*>(se_mean + 4 * qq);
-          s = fmaf(w.x, m.x, s); s = fmaf(w.y, m.y, s); s = fmaf(w.z, m.z, s); s = fmaf(w.w, m.w, s);
-        }
-      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-      if (f < F && sub == 0) se_hid[f] = fmaxf(s + p.se_b1[f], 0.f);
-    }
-  }
-  __syncthreads();
-  for (int c = tid; c < C; c += 256) {      // fc2 + sigmoid: one thread per channel, the F weights of a channel are contiguous
-    float s = p.se_b2[c];
-    for (int f = 0; f < F; ++f) s = fmaf(p.se_w2[(long)c * F + f], se_hid[f], s);
-    p.se_gate[(long)n * C + c] = fast_sigmoid(s);
-  }
-}
 
 // XCD-aware bijective block remap (same as the GEMM): consecutive logical blocks -- neighbouring output
 // positions, which share most of their input taps -- run on ONE XCD, so the k^3 re-reads hit that XCD's L2
@@ -303,24 +209,7 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(const DwArgs p) {
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int j = r; j < 256; j += p.CV) { s.x += stage[j].x; s.y += stage[j].y; s.z += stage[j].z; s.w += stage[j].w; }
       const int cvr = (int)((idx0 + r) % (unsigned)p.CV);
-      if (p.se_gate) {      // handed to the sample's last workgroup inside this launch: written through (see dw_st_sc1)
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.pool + ((long)n * nblk + lb) * p.C, 0, p.C * 4, 0x00020000);
-        dw_st_sc1(rs, (unsigned)cvr * 16u, s);
-      } else {
-        *reinterpret_cast<float4*>(p.pool + ((long)n * nblk + lb) * p.C + cvr * 4) = s;
-      }
-    }
-    if (p.se_gate) {        // workgroup-uniform
-      __shared__ int se_last;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains, then ONE lane signals for the workgroup
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(p.se_count + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        se_last = t == (unsigned)nblk - 1u;
-        if (se_last) __hip_atomic_store(p.se_count + n, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
-      }
-      __syncthreads();
-      if (se_last) se_gate_tail(p, n, nblk);
+      *reinterpret_cast<float4*>(p.pool + ((long)n * nblk + lb) * p.C + cvr * 4) = s;
     }
   }
 }
@@ -662,7 +551,6 @@ static int fill_args(const MspiDwConvDesc* d, DwArgs& a, const char* who) {
   a.per_sample = (long)To * Ho * Wo * a.CV;
   static const int unit_xcd = getenv("MSPI_DW_UNIT_XCD") ? atoi(getenv("MSPI_DW_UNIT_XCD")) : 1;
   a.unit_xcd = unit_xcd;
-  a.se_w1 = a.se_b1 = a.se_w2 = a.se_b2 = nullptr; a.se_gate = nullptr; a.se_count = nullptr; a.se_F = 0; a.se_inv = 0.f;
   MSPI_REQUIRE(a.per_sample < (1L << 31) - 256 && d->N < 65536, "%s: more than 2^31 outputs per sample", who);
   return MSPI_OK;
 }
@@ -682,17 +570,8 @@ static int strip_variant(const MspiDwConvDesc* d) {
   return -1;
 }
 
-struct SeFold { const float* w1; const float* b1; const float* w2; const float* b2; float* gate; unsigned* count; int F; float inv; };
-
-// the fold lives in the strip kernel (the one X3D's 3x3x3 channel-wise convs run on); the LDS / tile kernels keep plain pooling
-static bool se_fold_supported(const MspiDwConvDesc* d, int F) {
-  TileCfg tc;
-  LdsCfg lc;
-  return strip_variant(d) >= 0 && !lds_cfg(d, lc) && !tile_cfg(d, tc) && d->C <= SE_MAX_C && (d->C & 3) == 0 && F >= 1 && F <= SE_MAX_F;
-}
-
-static int dwconv_impl(const MspiDwConvDesc* d, const float* x, const float* w, const float* bias, float* y,
-                       float* pool, const SeFold* se, mspi_stream_t stream) {
+extern "C" int mspi_dwconv_fwd(const MspiDwConvDesc* d, const float* x, const float* w, const float* bias, float* y,
+                               float* pool, mspi_stream_t stream) {
   MSPI_REQUIRE(d && x && w && y, "mspi_dwconv_fwd: null argument");
   DwArgs a;
   int rc = fill_args(d, a, "mspi_dwconv_fwd");
@@ -700,10 +579,6 @@ static int dwconv_impl(const MspiDwConvDesc* d, const float* x, const float* w, 
   MSPI_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y) && (!bias || aligned16(bias)),
                "mspi_dwconv_fwd: pointers must be 16-B aligned");
   a.x = x; a.w = w; a.bias = bias; a.y = y; a.pool = pool;
-  if (se) {
-    a.se_w1 = se->w1; a.se_b1 = se->b1; a.se_w2 = se->w2; a.se_b2 = se->b2; a.se_gate = se->gate; a.se_count = se->count;
-    a.se_F = se->F; a.se_inv = se->inv;
-  }
   hipStream_t s = (hipStream_t)stream;
   const int strip = strip_variant(d);
   MSPI_REQUIRE(!pool || strip >= 0, "mspi_dwconv_fwd: SE pooling needs a (k,3,3)/(k,5,5)/(k,7,7) kernel with W-stride 1 or 2");
@@ -755,25 +630,6 @@ static int dwconv_impl(const MspiDwConvDesc* d, const float* x, const float* w, 
     hipLaunchKernelGGL((dw_kernel<false>), grid, dim3(256), 0, s, a);
   }
   return check_launch("mspi_dwconv_fwd");
-}
-
-extern "C" int mspi_dwconv_fwd(const MspiDwConvDesc* d, const float* x, const float* w, const float* bias, float* y,
-                               float* pool, mspi_stream_t stream) {
-  return dwconv_impl(d, x, w, bias, y, pool, nullptr, stream);
-}
-
-extern "C" int mspi_dwconv_se_supported(const MspiDwConvDesc* d, int32_t F) { return d && se_fold_supported(d, F) ? 1 : 0; }
-
-extern "C" int mspi_dwconv_se_fwd(const MspiDwConvDesc* d, const float* x, const float* w, const float* bias, float* y,
-                                  float* pool, float inv_count, const float* w1, const float* b1, const float* w2,
-                                  const float* b2, int32_t F, float* gate, uint32_t* counters, mspi_stream_t stream) {
-  MSPI_REQUIRE(d && pool && w1 && b1 && w2 && b2 && gate && counters, "mspi_dwconv_se_fwd: null argument");
-  MSPI_REQUIRE(se_fold_supported(d, F), "mspi_dwconv_se_fwd: descriptor outside the folded kernel's range (mspi_dwconv_se_supported)");
-  MSPI_REQUIRE(aligned16(pool) && aligned16(w1) && (reinterpret_cast<uintptr_t>(counters) & 3u) == 0,
-               "mspi_dwconv_se_fwd: pool / w1 must be 16-B aligned");
-  MSPI_REQUIRE((long)mspi_dwconv_pool_rows(d) * d->C * 4 < (1L << 31), "mspi_dwconv_se_fwd: partial rows of one sample exceed 2 GB");
-  const SeFold se = {w1, b1, w2, b2, gate, counters, F, inv_count};
-  return dwconv_impl(d, x, w, bias, y, pool, &se, stream);
 }
 
 extern "C" int mspi_dwconv_pool_rows(const MspiDwConvDesc* d) {

@@ -846,29 +846,8 @@ def _dw_desc(x, k, s, p, out_ld):
     return d
 
 
-# Arrival counters of the folded squeeze-excite launches (mspi_dwconv_se_fwd): zero before and after every launch, so ONE
-# buffer serves all launches ordered on one stream; launches that can overlap need their own.  Keyed by the stream the launch
-# goes to -- a GraphPipeline slot warms up and captures on its own stream, so the graphs in flight never share a buffer -- and
-# created (zeroed) on first use, which for a graph is the eager warm-up forward in front of the capture.
-_SE_COUNTERS = {}
-SE_FOLD = _os.environ.get("MSPI_SE_FOLD", "1") != "0"       # A/B switch: 0 = separate mspi_se_gate launches
-SE_MAX_N = 256
-
-
-def _se_counters(device):
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _SE_COUNTERS.get(key)
-    if buf is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None         # never allocate + memset inside a capture: the caller falls back to the two-launch form
-        buf = _SE_COUNTERS[key] = torch.zeros(SE_MAX_N, dtype=torch.int32, device=device)
-    return buf
-
-
-def dwconv(x, pk, out=None, pool=False, act=None, se=None):
-    """pool=True (X3D squeeze-excite): also returns the [N, rows, C] partial sums of the pre-activation output.
-    se=(w1, b1, w2, b2) with pool=True: returns (out, gate[N, C]) -- the gate computed inside the same launch where the
-    kernel supports it (mspi_dwconv_se_fwd), by a following mspi_se_gate launch otherwise."""
+def dwconv(x, pk, out=None, pool=False, act=None):
+    """pool=True (X3D squeeze-excite): also returns the [N, rows, C] partial sums of the pre-activation output."""
     lib = _lib.load()
     _need_gpu(x.buf)
     if x.Cs != pk.c_s:
@@ -887,20 +866,6 @@ def dwconv(x, pk, out=None, pool=False, act=None, se=None):
             raise MspiError("dwconv: squeeze-excite pooling is not supported for kernel %s stride %s" % (pk.k, pk.stride))
         part = torch.empty(x.N, rows, pk.c_s, dtype=torch.float32, device=x.buf.device)
     taps = pk.k[0] * pk.k[1] * pk.k[2]
-    inv = 1.0 / (To * Ho * Wo)
-    if pool and se is not None:
-        w1, b1, w2, b2 = se
-        cnt = _se_counters(x.buf.device) if SE_FOLD and x.N <= SE_MAX_N and lib.mspi_dwconv_se_supported(C.byref(d), w1.shape[0]) else None
-        if cnt is None:
-            out, part = dwconv(x, pk, out=out, pool=True, act=act)
-            return out, se_gate(part, inv, w1, b1, w2, b2)
-        gate = torch.empty(x.N, pk.c_s, dtype=torch.float32, device=x.buf.device)
-        with _Timed("dwconv_se", 2.0 * out.M * taps * pk.c, 4.0 * (x.M + out.M) * pk.c,
-                    "in=%s C=%d k=%s s=%s" % ((x.N, x.T, x.H, x.W), pk.c, pk.k, pk.stride)):
-            check(lib.mspi_dwconv_se_fwd(C.byref(d), x.ptr, pk.w.data_ptr(), pk.bias.data_ptr(), out.ptr, part.data_ptr(), inv,
-                                         w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w1.shape[0],
-                                         gate.data_ptr(), cnt.data_ptr(), _stream()), "mspi_dwconv_se_fwd")
-        return out, gate
     with _Timed("dwconv_pool" if pool else "dwconv", 2.0 * out.M * taps * pk.c, 4.0 * (x.M + out.M) * pk.c,
                 "in=%s C=%d k=%s s=%s" % ((x.N, x.T, x.H, x.W), pk.c, pk.k, pk.stride)):
         check(lib.mspi_dwconv_fwd(C.byref(d), x.ptr, pk.w.data_ptr(), pk.bias.data_ptr(), out.ptr,

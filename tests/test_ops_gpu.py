@@ -178,90 +178,6 @@ def test_dwconv_pool_maxpool(dev, case):
         _close(mp.as_ncdhw(C), F.max_pool3d(x, k, s, p), 0, "maxpool")
 
 
-SE_FOLD_CASES = [   # N, C, T, H, W, stride, F: the X3D-L stage shapes (reduced T / batch) + ragged ones
-    (2, 54, 4, 28, 28, 2, 8), (3, 108, 5, 28, 28, 1, 8), (8, 216, 16, 14, 14, 1, 16), (8, 432, 16, 7, 7, 1, 32),
-    (2, 432, 3, 14, 14, 2, 32), (1, 20, 2, 5, 9, 1, 3), (5, 512, 2, 7, 7, 1, 64),
-]
-
-
-@pytest.mark.parametrize("case", SE_FOLD_CASES)
-def test_dwconv_se_fold(dev, case):
-    """Depthwise 3x3x3 + pooling + squeeze-excite gate in one launch (mspi_dwconv_se_fwd) against conv3d / SE in torch
-    (SlowFast/resnet_helper.py:27-73, 313-327) and against the two-launch form; the launch is repeated on the SAME buffers
-    with new inputs (a hipGraph replay's situation: a stale partial row of the previous launch would show), the counters are
-    zero afterwards, and the result is bitwise reproducible."""
-    import ctypes
-    from mspi_amd import engine as E, _lib
-    N, C, T, H, W, st, Fh = case
-    g = torch.Generator().manual_seed(C + T)
-    k, s, p = (3, 3, 3), (1, st, st), (1, 1, 1)
-    w = torch.randn(C, 1, *k, generator=g) / math.sqrt(27)
-    b = torch.randn(C, generator=g)
-    cs = (C + 3) // 4 * 4
-    w1 = torch.zeros(Fh, cs); w1[:, :C] = torch.randn(Fh, C, generator=g) / 3
-    w2 = torch.zeros(cs, Fh); w2[:C] = torch.randn(C, Fh, generator=g) / 2
-    b1, b2 = torch.randn(Fh, generator=g), torch.zeros(cs)
-    b2[:C] = torch.randn(C, generator=g)
-    se = tuple(t.to(dev).contiguous() for t in (w1, b1, w2, b2))
-    pk = E.pack_dwconv(w, b, None, s, p, E.ACT_NONE, device=dev)
-    lib = _lib.load()
-    xs = [torch.randn(N, C, T, H, W, generator=g) * (1 + i) for i in range(3)]
-    xin = _cl(xs[0], dev)
-    d = E._dw_desc(xin, k, s, p, xin.ld)
-    assert lib.mspi_dwconv_se_supported(ctypes.byref(d), Fh) == 1
-    out = gate = None
-    for i, x in enumerate(xs * 2):
-        xin.buf.copy_(_cl(x, dev).buf)
-        if out is None:
-            out, gate = E.dwconv(xin, pk, pool=True, se=se)
-            gate_ptr = gate.data_ptr()
-        else:       # same input / output / partial-row / gate addresses as the first launch
-            torch.cuda.synchronize()
-            out, gate2 = E.dwconv(xin, pk, out=out, pool=True, se=se)
-            gate = gate2
-        ref = F.conv3d(x, w, b, s, p, 1, C)
-        inv = 1.0 / (ref.shape[2] * ref.shape[3] * ref.shape[4])
-        gref = torch.sigmoid(F.linear(F.relu(F.linear(ref.sum((2, 3, 4)) * inv, w1[:, :C], b1)), w2[:C], b2[:C]))
-        _close(out.as_ncdhw(C), ref, 2e-5, "dwconv (se fold) %d" % i)
-        _close(gate[:, :C], gref, 2e-5, "folded se gate %d" % i)
-        o2, part = E.dwconv(xin, pk, pool=True, act=E.ACT_NONE)
-        g2 = E.se_gate(part, inv, *se)
-        _close(gate, g2.cpu(), 1e-5, "folded vs two-launch gate %d" % i)      # the two forms add the rows in different orders
-        o3, gate3 = E.dwconv(xin, pk, pool=True, se=se)
-        assert torch.equal(gate, gate3) and torch.equal(out.buf, o3.buf)        # fixed summation order whatever the arrival order
-    torch.cuda.synchronize()
-    assert all(int(v.abs().max()) == 0 for v in E._SE_COUNTERS.values())
-
-
-def test_dwconv_se_fold_two_streams(dev):
-    """Two streams run folded launches at the same time: each stream has arrival counters of its own (engine._se_counters)."""
-    from mspi_amd import engine as E
-    N, C, T, H, W, Fh = 8, 216, 16, 14, 14, 16
-    g = torch.Generator().manual_seed(7)
-    k, s, p = (3, 3, 3), (1, 1, 1), (1, 1, 1)
-    w = torch.randn(C, 1, *k, generator=g) / math.sqrt(27)
-    b = torch.randn(C, generator=g)
-    se = tuple(t.to(dev) for t in (torch.randn(Fh, C, generator=g) / 3, torch.randn(Fh, generator=g),
-                                   torch.randn(C, Fh, generator=g) / 2, torch.randn(C, generator=g)))
-    pk = E.pack_dwconv(w, b, None, s, p, E.ACT_NONE, device=dev)
-    xa, xb = (_cl(torch.randn(N, C, T, H, W, generator=g), dev) for _ in range(2))
-    ga = E.dwconv(xa, pk, pool=True, se=se)[1].clone()
-    gb = E.dwconv(xb, pk, pool=True, se=se)[1].clone()
-    torch.cuda.synchronize()
-    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
-    res = []
-    for _ in range(20):
-        with torch.cuda.stream(sa):
-            ra = E.dwconv(xa, pk, pool=True, se=se)[1]
-        with torch.cuda.stream(sb):
-            rb = E.dwconv(xb, pk, pool=True, se=se)[1]
-        res.append((ra, rb))
-    torch.cuda.synchronize()
-    for ra, rb in res:
-        assert torch.equal(ra, ga) and torch.equal(rb, gb)
-    assert len(E._SE_COUNTERS) >= 3 and all(int(v.abs().max()) == 0 for v in E._SE_COUNTERS.values())
-
-
 def test_se_gate(dev):
     from mspi_amd import engine as E
     g = torch.Generator().manual_seed(2)
