@@ -513,9 +513,13 @@ static bool tile_cfg(const MspiDwConvDesc* d, TileCfg& c) {
   if (off || d->kH != d->kW || d->strH != d->strW) return false;
   if (!((d->kW == 3 && (d->strW == 1 || d->strW == 2)) || (d->kW == 7 && d->strW == 1))) return false;
   static const bool all = getenv("MSPI_DW_TILE_ALL") != nullptr;
-  // measured (profiles/r01): the tile kernel wins on 7x7 with maps >= 28 wide (172 -> 134 us at 56^2 x 96), the strip
-  // kernel on 3x3x3 and on the small maps, where one round of blocks makes latency, not traffic, the cost
-  if (!all && !(d->kW == 7 && d->W >= 28)) return false;
+  // measured (profiles/r01): the tile kernel wins on 7x7 with maps >= 28 wide (172 -> 134 us at 56^2 x 96), the strip kernel on
+  // the small 7x7 maps, where one round of blocks makes latency, not traffic, the cost.  X3D's 3x3x3 (round 3, r03_dw3_tile.txt):
+  // alone the two are equal (X3D-L path 4.34 vs 4.37 ms), but the tile kernel issues a third of the strip kernel's vector loads
+  // (weights from LDS, rows shared by two output rows), so beside other kernels -- the way the model runs -- it wins: 0.437 vs
+  // 0.409 of HBM peak with four batches in flight, bench line +1.6 %.  MSPI_DW_TILE3=0: strip kernel for 3x3 (A/B).
+  static const bool tile3 = !(getenv("MSPI_DW_TILE3") && atoi(getenv("MSPI_DW_TILE3")) == 0);
+  if (!all && !(d->kW == 7 && d->W >= 28) && !(d->kW == 3 && tile3)) return false;
   const int Ho = (d->H + 2 * d->padH - d->kH) / d->strH + 1, Wo = (d->W + 2 * d->padW - d->kW) / d->strW + 1;
   const int To = (d->T + 2 * d->padT - d->kT) / d->strT + 1;
   c.K = d->kW; c.STR = d->strW;

@@ -93,29 +93,56 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // One workgroup per sample.  pool holds `rows` partial sums per channel (one per dwconv block, fixed order):
 // they are summed here in a fixed order too (thread groups over row ranges, then a serial combine), so the
 // squeeze-excite path is bitwise reproducible.  Then fc1 (C->F) by wavefront-reduced dots, ReLU, fc2, sigmoid.
+// The kernel is ONE latency chain (8 workgroups on the chip): 29 launches of an X3D-L forward, 10.6 us each when the rows
+// were read in batches of 8 (6 dependent batches at C = 216) and the fc weights were fetched where they are used (2 more
+// round trips).  PRE (C <= 512, F <= 32): 24 rows in flight per thread (2 batches) and both weight matrices requested up front,
+// into registers, so that the chain is the two row batches and the LDS phases.
+template <bool PRE>
 __global__ __launch_bounds__(1024) void se_gate_kernel(const float* __restrict__ pool, int rows, float inv_count,
                                                       const float* __restrict__ w1, const float* __restrict__ b1,
                                                       const float* __restrict__ w2, const float* __restrict__ b2,
                                                       float* __restrict__ gate, int C, int F) {
   extern __shared__ float sm[];  // [G*C] partial sums, then [C] means, [F] hidden
   const int n = blockIdx.x;
-  const int G = C <= 1024 ? 1024 / C : 1;   // row groups: 1024 threads, because the kernel is one latency chain per
-                                            // thread (189 partial rows at C = 216: 24 dependent load batches with 256 threads)
+  const int G = C <= 1024 ? 1024 / C : 1;   // row groups: 1024 threads, because the kernel is one latency chain per thread
   float* part = sm;
   float* mean = sm + G * C;
   float* hid = mean + C;
   const float* pb = pool + (long)n * rows * C;
-  // 8 independent accumulators per thread keep 8 loads in flight; the combine order is fixed, so still bitwise
-  // reproducible (a single dependent add chain over ~700 partial rows made this tiny kernel cost 55 us).
-  auto col_sum = [&](int c, int r0, int step) {
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int r = r0;
-    for (; r + 7 * step < rows; r += 8 * step) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NB = PRE ? 24 : 8;          // rows in flight per thread
+  float w1r[PRE ? 2 : 1][PRE ? 8 : 1];      // fc1: wave -> hidden units wave, wave + 16; lane -> channels lane + 64 j
+  float w2r[PRE ? 32 : 1];                  // fc2: thread -> channel threadIdx.x (C <= 512 < 1024 threads)
+  float b2r = 0.f;
+  if (PRE) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += pb[(long)(r + u * step) * C + c];
+    for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int f = wave + 16 * fi, c = lane + 64 * j;
+        w1r[fi][j] = (f < F && c < C) ? w1[(long)f * C + c] : 0.f;
+      }
+    const int c2 = min((int)threadIdx.x, C - 1);
+#pragma unroll
+    for (int f = 0; f < 32; ++f) w2r[f] = w2[(long)c2 * F + min(f, F - 1)];
+    b2r = b2[c2];
+  }
+  // NB independent loads per thread and batch, 4 accumulators; the combine order is fixed, so still bitwise reproducible
+  // (a single dependent add chain over ~700 partial rows made this tiny kernel cost 55 us).
+  auto col_sum = [&](int c, int r0, int step) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < rows; r += NB * step) {
+      float v[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int rr = r + u * step;
+        v[u] = pb[(long)min(rr, rows - 1) * C + c];
+        if (rr >= rows) v[u] = 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) a[u & 3] += v[u];
     }
-    for (int u = 0; r < rows; r += step, ++u) a[u] += pb[(long)r * C + c];
-    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    return (a[0] + a[1]) + (a[2] + a[3]);
   };
   if (G > 1) {
     const int c = threadIdx.x % C, g = threadIdx.x / C;
@@ -130,18 +157,41 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(const float* __restrict__
     mean[c] = s * inv_count;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int f = wave; f < F; f += 16) {
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s = fmaf(w1[(long)f * C + c], mean[c], s);
-    s = wave_sum(s);
-    if (lane == 0) hid[f] = fmaxf(s + b1[f], 0.f);
+  if (PRE) {
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi) {
+      const int f = wave + 16 * fi;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = lane + 64 * j;
+        s = fmaf(w1r[fi][j], c < C ? mean[c] : 0.f, s);
+      }
+      s = wave_sum(s);
+      if (lane == 0 && f < F) hid[f] = fmaxf(s + b1[f], 0.f);
+    }
+  } else {
+    for (int f = wave; f < F; f += 16) {
+      float s = 0.f;
+      for (int c = lane; c < C; c += 64) s = fmaf(w1[(long)f * C + c], mean[c], s);
+      s = wave_sum(s);
+      if (lane == 0) hid[f] = fmaxf(s + b1[f], 0.f);
+    }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 1024) {
-    float s = b2[c];
-    for (int f = 0; f < F; ++f) s = fmaf(w2[(long)c * F + f], hid[f], s);
-    gate[(long)n * C + c] = fast_sigmoid(s);
+  if (PRE) {
+    if ((int)threadIdx.x < C) {
+      float s = b2r;
+#pragma unroll
+      for (int f = 0; f < 32; ++f) s = fmaf(w2r[f], f < F ? hid[f] : 0.f, s);
+      gate[(long)n * C + threadIdx.x] = fast_sigmoid(s);
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += 1024) {
+      float s = b2[c];
+      for (int f = 0; f < F; ++f) s = fmaf(w2[(long)c * F + f], hid[f], s);
+      gate[(long)n * C + c] = fast_sigmoid(s);
+    }
   }
 }
 
@@ -403,7 +453,9 @@ extern "C" int mspi_se_gate(const float* pool, int32_t rows, float inv_count, co
   const int G = C <= 1024 ? 1024 / C : 1;
   const size_t lds = (size_t)(G * C + C + F) * sizeof(float);
   MSPI_REQUIRE(N > 0 && rows > 0 && C > 0 && F > 0 && lds <= 64 * 1024, "mspi_se_gate: bad extent");
-  hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(1024), lds, (hipStream_t)stream, pool, rows, inv_count, w1, b1, w2,
+  if (C <= 512 && F <= 32) hipLaunchKernelGGL((se_gate_kernel<true>), dim3(N), dim3(1024), lds, (hipStream_t)stream, pool, rows, inv_count, w1, b1, w2,
+                     b2, gate, C, F);
+  else hipLaunchKernelGGL((se_gate_kernel<false>), dim3(N), dim3(1024), lds, (hipStream_t)stream, pool, rows, inv_count, w1, b1, w2,
                      b2, gate, C, F);
   return check_launch("mspi_se_gate");
 }
