@@ -20,5 +20,7 @@ for k, cs in acc.items():
     if busy <= 0:
         continue
     rows.append((busy * b[1], k, b[1], busy, gui, busy * 8 / (gui * 1024)))
-for _, k, n, busy, gui, frac in sorted(rows, reverse=True)[:14]:
+rows.sort(reverse=True)
+keep = rows[:14] + [r for r in rows[14:] if "attn" in r[1]]      # the attention kernels are a north-star target: always listed
+for _, k, n, busy, gui, frac in keep:
     print("%s,%s,%d,%.0f,%.0f,%.4f" % (sys.argv[2], k.replace(",", ";"), n, busy, gui, frac))
