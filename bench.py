@@ -40,9 +40,10 @@ def parse():
                     help="launch eagerly instead of replaying a hipGraph (the clip loop's default launch path)")
     ap.add_argument("--no-eager-line", action="store_true", help="skip the short eager-launch measurement reported as `eager` beside "
                     "the hipGraph number (single-GPU runs only)")
-    ap.add_argument("--inflight", type=int, default=2, help="hipGraphs of the forward kept in flight (mspi_amd.runtime.GraphPipeline): "
+    ap.add_argument("--inflight", type=int, default=None, help="hipGraphs of the forward kept in flight (mspi_amd.runtime.GraphPipeline): "
                     "consecutive steps (batches) replay round-robin on this many streams, so the low-occupancy tail of one batch "
-                    "overlaps the head of the next (each step is still one full forward of one batch; 1 = one batch at a time)")
+                    "overlaps the head of the next (each step is still one full forward of one batch; 1 = one batch at a time). "
+                    "Default: 2 (forked graphs) in a single process, 3 (linear graphs) under a process group")
     ap.add_argument("--stream-layouts", type=int, default=4, help="stream layouts tried for the in-flight graphs during the untimed "
                     "set-up (which streams share a hardware queue decides how well two batches overlap); 1 = take the first")
     ap.add_argument("--no-autotune", action="store_true", help="keep the library's tile heuristic (default: time the "
@@ -85,10 +86,16 @@ if ARGS is not None and ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
 if ARGS is not None and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("MSPI_BENCH_FORCE_DIST"):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
 elif ARGS is not None:
-    # with a process group RCCL's own streams take hardware queues: one rank through the whole RCCL path on a one-GPU box
-    # (tools/dist_rehearsal.sh, profiles/r03_dist_rehearsal.txt): 4 queues 96.8 %, 5 queues 97.9 %, 6: 84.0 %, 8: 91.2 % of the
-    # single-process line; the stream-layout probe runs after init_process_group + the weight broadcast in every case
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
+    # With a process group RCCL's own streams take hardware queues, and which queue a graph BRANCH lands on then decides up to
+    # 20 % of a rank's rate (forked graphs, two in flight, 5 queues: layouts 78.7 / 63.8 / 77.4 / 74.6 batches/s; best 97.5 % of
+    # the single-process line).  Ranks therefore replay LINEAR graphs (MSPI_STREAMS=0: no fork inside a batch), three in
+    # flight, on the runtime's default queue count: one rank through the whole RCCL path on a one-GPU box reaches 99.4 % of the
+    # single-process line and all four stream layouts are equal (82.2 / 81.7 / 82.2 / 81.5) -- tools/dist_rehearsal.sh,
+    # profiles/r03_dist_rehearsal.txt.  Explicit settings in the environment / on the command line win.
+    os.environ.setdefault("MSPI_STREAMS", "0")
+if ARGS is not None and ARGS.inflight is None:
+    ARGS.inflight = 3 if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("MSPI_BENCH_FORCE_DIST")) and \
+        os.environ.get("MSPI_STREAMS") == "0" else 2
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -453,8 +460,9 @@ def main():
                                "forward), batch %d/GPU, clips 3x16x%dx%d, spectrogram 1x257x%d, inputs resident in HBM"
                                % (label, B, S, S, args.wa),
                    "global_batch": world * B,
-                   "launch": "eager" if not graph_mode else "hipGraph replay (mspi_amd.runtime.GraphPipeline), %d batch%s in flight"
-                             % (depth, "es" if depth > 1 else ""),
+                   "launch": "eager" if not graph_mode else "hipGraph replay (mspi_amd.runtime.GraphPipeline), %d batch%s in flight%s"
+                             % (depth, "es" if depth > 1 else "",
+                                ", linear graphs (no branch streams)" if os.environ.get("MSPI_STREAMS") == "0" else ""),
                    "stream_layout": layout_main,
                    "parallelism": "clip-sharded x%d (weights broadcast once, maps gathered per step over RCCL)" % world
                    if multi else "single GPU"},
