@@ -67,8 +67,11 @@ THIN_DEFAULT = True   # without autotuning: take the thin kernel wherever it app
 THIN_ENABLED = _os.environ.get("MSPI_THIN", "1") != "0"   # A/B switch
 
 
+_TUNE_LOG = _os.environ.get("MSPI_TUNE_LOG") == "1"
+
+
 def _tune_conv(launch, key, candidates):
-    best, best_t = -1, float("inf")
+    best, best_t, times = -1, float("inf"), []
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for tile in candidates:
         if launch(tile) != 0:
@@ -79,9 +82,13 @@ def _tune_conv(launch, key, candidates):
         e1.record()
         e1.synchronize()
         t = e0.elapsed_time(e1)
+        times.append((tile, t / AUTOTUNE["reps"]))
         if t < best_t:
             best, best_t = tile, t
     AUTOTUNE["cache"][key] = best
+    if _TUNE_LOG:       # MSPI_TUNE_LOG=1: every candidate's time (ms per launch, alone on the chip) to stderr
+        import sys
+        print("[tune] %s -> %d  %s" % (key, best, " ".join("%d:%.4f" % tt for tt in times)), file=sys.stderr)
     return best
 
 
