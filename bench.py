@@ -214,7 +214,8 @@ def dry_run(args, rank, world):
         print(json.dumps({"metric": "clips_per_sec", "value": None, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dry_run": True, "data": "none",
-                          "config": {"workload": "dry run of the launch path: no GPU work", "global_batch": world * args.batch}}))
+                          "config": {"workload": "dry run of the launch path: no GPU work", "global_batch": world * args.batch,
+                                     "launch": "%d batches in flight, %s graphs" % (args.inflight, "linear" if os.environ.get("MSPI_STREAMS") == "0" else "forked")}}))
     if multi:
         dist.destroy_process_group()
 

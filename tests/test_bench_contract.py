@@ -36,6 +36,9 @@ def test_gpus_n_without_a_launcher_starts_n_ranks(n):
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == n and d["config"]["global_batch"] == 8 * n and d["dry_run"] is True and d["steps"] == 3
+    # under a process group a rank replays LINEAR graphs, three in flight (no branch streams whose hardware-queue placement
+    # could differ between ranks: DESIGN.md section 6)
+    assert d["config"]["launch"] == "3 batches in flight, linear graphs"
 
 
 def test_world_size_mismatch_is_an_error():
